@@ -1,0 +1,294 @@
+// oracle/ref_shim.cpp — TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin C-ABI wrapper around the *unmodified* reference classes, compiled together
+// with the reference's own source files where they lie under /root/reference by
+// oracle/Makefile into oracle/_ref/libria_ref.so (git-ignored).  It exists only in
+// the build container: it pins the CPU restatement in oracle/ria_oracle.c and
+// generates the golden vectors under tests/golden/ (oracle/gen_golden.py).
+//
+// Nothing here is copied from the reference; it only *calls* it:
+//   OFDMChirpWaveform   src/waveform/ofdm_chirp_waveform.cpp:391-468 (process)
+//   v2::encodeFixedFrame/decodeFixedFrame   src/protocol/frame_v2.cpp:1285-1883
+//   LDPCEncoder/LDPCDecoder   src/fec/ldpc_encoder.cpp, src/fec/ldpc_decoder.cpp
+//   sim::WattersonChannel   src/sim/hf_channel.hpp:35-303
+//   sync::ZCSync / sync::ChirpSync   src/sync/zc_sync.hpp, src/sync/chirp_sync.hpp
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <span>
+#include <string>
+#include <vector>
+
+// The demodulator keeps its estimator state in a private pimpl; the golden
+// fixtures need that state (H, noise variance, phase slope) as stage taps.
+#define private public
+#include "ultra/ofdm.hpp"
+#undef private
+#include "ofdm/demodulator_impl.hpp"
+
+#include "ultra/fec.hpp"
+#include "ultra/logging.hpp"
+#include "ultra/types.hpp"
+#include "fec/frame_interleaver.hpp"
+#include "fec/ldpc_codec.hpp"
+#include "protocol/frame_v2.hpp"
+#include "sim/hf_channel.hpp"
+#include "sync/chirp_sync.hpp"
+#include "sync/zc_sync.hpp"
+#define private public
+#include "waveform/ofdm_chirp_waveform.hpp"
+#undef private
+
+using namespace ultra;
+
+namespace {
+
+ModemConfig named_config(int mod, int rate) {
+    // SURVEY.md Appendix C / tools/test_waveform_simple.cpp:109-121
+    ModemConfig cfg;
+    cfg.sample_rate = 48000;
+    cfg.center_freq = 1500;
+    cfg.fft_size = 1024;
+    cfg.num_carriers = 59;
+    cfg.cp_mode = CyclicPrefixMode::LONG;
+    cfg.use_pilots = true;
+    cfg.modulation = static_cast<Modulation>(mod);
+    cfg.code_rate = static_cast<CodeRate>(rate);
+    return cfg;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ref_quiet(void) { ultra::g_log_level = LogLevel::NONE; }
+
+// ---------------------------------------------------------------- TX
+// Builds one connected-mode data frame: light preamble (2 LTS) + modulated
+// fixed 4-CW frame.  Returns sample count (or -needed if max_samples too small).
+int ref_tx_frame(int mod, int rate, const uint8_t* payload, int payload_len, int seq,
+                 float* samples_out, int max_samples,
+                 uint8_t* frame_info_out, int max_info,   // 4*bytes_per_cw, zero padded
+                 uint8_t* coded_out, int max_coded,       // 324 interleaved coded bytes
+                 int* bits_per_symbol_out) {
+    ref_quiet();
+    ModemConfig cfg = named_config(mod, rate);
+    OFDMChirpWaveform tx(cfg);
+    tx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    CodeRate cr = static_cast<CodeRate>(rate);
+
+    Bytes pl(payload, payload + payload_len);
+    auto frame = protocol::v2::makeFixedDataFrame("TEST", "RX", static_cast<uint16_t>(seq), pl, cr);
+    Bytes fd = frame.serialize();
+
+    int pilots = (cfg.num_carriers + tx.config_.pilot_spacing - 1) / tx.config_.pilot_spacing;
+    int data_carriers = cfg.num_carriers - pilots;
+    size_t bps = data_carriers * getBitsPerSymbol(static_cast<Modulation>(mod));
+    if (bits_per_symbol_out) *bits_per_symbol_out = static_cast<int>(bps);
+
+    Bytes enc = protocol::v2::encodeFixedFrame(fd, cr, true, bps);
+    Samples pre = tx.generateDataPreamble();
+    Samples dat = tx.modulate(enc);
+
+    size_t info_bytes = 4 * protocol::v2::getBytesPerCodeword(cr);
+    if (frame_info_out) {
+        Bytes padded = fd;
+        padded.resize(info_bytes, 0);
+        std::memcpy(frame_info_out, padded.data(), std::min<size_t>(info_bytes, max_info));
+    }
+    if (coded_out) std::memcpy(coded_out, enc.data(), std::min<size_t>(enc.size(), max_coded));
+
+    int n = static_cast<int>(pre.size() + dat.size());
+    if (n > max_samples) return -n;
+    std::memcpy(samples_out, pre.data(), pre.size() * sizeof(float));
+    std::memcpy(samples_out + pre.size(), dat.data(), dat.size() * sizeof(float));
+    return n;
+}
+
+// Raw bytes → fixed-frame encode (no frame header/CRC added): LDPC x4 + interleave.
+int ref_encode_fixed_frame(const uint8_t* info, int n_info, int rate, int ch_interleave, int bps,
+                           uint8_t* coded_out, int max_coded) {
+    ref_quiet();
+    Bytes fd(info, info + n_info);
+    Bytes enc = protocol::v2::encodeFixedFrame(fd, static_cast<CodeRate>(rate), ch_interleave != 0, bps);
+    std::memcpy(coded_out, enc.data(), std::min<size_t>(enc.size(), max_coded));
+    return static_cast<int>(enc.size());
+}
+
+// Coded bytes → audio: light preamble + modulate (no LDPC).
+int ref_modulate(int mod, int rate, const uint8_t* coded, int n_coded, float* samples_out, int max_samples) {
+    ref_quiet();
+    ModemConfig cfg = named_config(mod, rate);
+    OFDMChirpWaveform tx(cfg);
+    tx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    Bytes enc(coded, coded + n_coded);
+    Samples pre = tx.generateDataPreamble();
+    Samples dat = tx.modulate(enc);
+    int n = static_cast<int>(pre.size() + dat.size());
+    if (n > max_samples) return -n;
+    std::memcpy(samples_out, pre.data(), pre.size() * sizeof(float));
+    std::memcpy(samples_out + pre.size(), dat.data(), dat.size() * sizeof(float));
+    return n;
+}
+
+// ---------------------------------------------------------------- channel
+// kind: 0 awgn, 1 good, 2 moderate, 3 poor, 4 flutter  (hf_channel.hpp:411-488)
+int ref_channel(int kind, float snr_db, uint32_t seed, const float* in, int n, float* out) {
+    ref_quiet();
+    sim::WattersonChannel::Config c;
+    switch (kind) {
+        case 0: c = sim::itu_r_f1487::awgn(snr_db); break;
+        case 1: c = sim::itu_r_f1487::good(snr_db); break;
+        case 2: c = sim::itu_r_f1487::moderate(snr_db); break;
+        case 3: c = sim::itu_r_f1487::poor(snr_db); break;
+        default: c = sim::itu_r_f1487::flutter(snr_db); break;
+    }
+    sim::WattersonChannel ch(c, seed);
+    Samples o = ch.process(SampleSpan(in, n));
+    std::memcpy(out, o.data(), n * sizeof(float));
+    return n;
+}
+
+// ---------------------------------------------------------------- RX demod
+// aux_out[0..7] = {snr_db, cfo_hz_out, fading_index, noise_variance, lts_phase_slope,
+//                  estimated_snr_linear, freq_correction_phase, snr_symbol_count}
+// h_out: 59 complex (re,im) channel_estimate in logical carrier order after the frame.
+int ref_rx_process(int mod, int rate, const float* samples, int n, float cfo_hz,
+                   long long abs_pos, int use_abs,
+                   float* llr_out, int max_llr, float* aux_out, float* h_out) {
+    ref_quiet();
+    ModemConfig cfg = named_config(mod, rate);
+    OFDMChirpWaveform rx(cfg);
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    rx.reset();
+    if (use_abs) rx.setAbsoluteTrainingPosition(static_cast<size_t>(abs_pos));
+    rx.setFrequencyOffset(cfo_hz);
+    bool ok = rx.process(SampleSpan(samples, n));
+    std::vector<float> soft = rx.getSoftBits();
+    int m = static_cast<int>(soft.size());
+    if (llr_out) std::memcpy(llr_out, soft.data(), std::min(m, max_llr) * sizeof(float));
+    auto* impl = rx.demodulator_->impl_.get();
+    if (aux_out) {
+        aux_out[0] = rx.estimatedSNR();
+        aux_out[1] = rx.demodulator_->getFrequencyOffset();
+        aux_out[2] = impl->last_fading_index;
+        aux_out[3] = impl->noise_variance;
+        aux_out[4] = impl->lts_phase_slope;
+        aux_out[5] = impl->estimated_snr_linear;
+        aux_out[6] = impl->freq_correction_phase;
+        aux_out[7] = static_cast<float>(impl->snr_symbol_count);
+    }
+    if (h_out) {
+        for (size_t i = 0; i < impl->all_carrier_fft_indices.size(); ++i) {
+            Complex h = impl->channel_estimate[impl->all_carrier_fft_indices[i]];
+            h_out[2 * i] = h.real();
+            h_out[2 * i + 1] = h.imag();
+        }
+    }
+    return ok ? m : -m;
+}
+
+// ---------------------------------------------------------------- decode
+// data_out: 4*bytes_per_cw, ok_out: 4
+int ref_decode_fixed_frame(const float* llr, int n, int rate, int ch_deint, int bps,
+                           uint8_t* data_out, uint8_t* ok_out) {
+    ref_quiet();
+    std::vector<float> soft(llr, llr + n);
+    CodeRate cr = static_cast<CodeRate>(rate);
+    auto st = protocol::v2::decodeFixedFrame(soft, cr, ch_deint != 0, bps);
+    size_t bpc = protocol::v2::getBytesPerCodeword(cr);
+    int good = 0;
+    for (int cw = 0; cw < 4; ++cw) {
+        ok_out[cw] = st.decoded[cw] ? 1 : 0;
+        std::memset(data_out + cw * bpc, 0, bpc);
+        if (st.decoded[cw] && st.data[cw].size() >= bpc) {
+            std::memcpy(data_out + cw * bpc, st.data[cw].data(), bpc);
+            ++good;
+        }
+    }
+    return good;
+}
+
+int ref_ldpc_decode(int rate, const float* llr, int n, int max_iter, float factor,
+                    uint8_t* out, int max_out, int* iters) {
+    LDPCDecoder dec(static_cast<CodeRate>(rate));
+    dec.setMaxIterations(max_iter);
+    dec.setMinSumFactor(factor);
+    Bytes b = dec.decodeSoft(std::span<const float>(llr, n));
+    std::memcpy(out, b.data(), std::min<size_t>(b.size(), max_out));
+    if (iters) *iters = dec.lastIterations();
+    return dec.lastDecodeSuccess() ? static_cast<int>(b.size()) : -static_cast<int>(b.size());
+}
+
+int ref_ldpc_encode(int rate, const uint8_t* in, int n, uint8_t* out, int max_out) {
+    LDPCEncoder enc(static_cast<CodeRate>(rate));
+    Bytes b = enc.encode(ByteSpan(in, n));
+    std::memcpy(out, b.data(), std::min<size_t>(b.size(), max_out));
+    return static_cast<int>(b.size());
+}
+
+int ref_recommended_iterations(int rate) {
+    return fec::LDPCCodec::getRecommendedIterations(static_cast<CodeRate>(rate));
+}
+
+// perm_out[i] = ChannelInterleaver permutation_[i] via a one-hot probe.
+int ref_channel_interleaver_perm(int bps, int total, int* inv_out) {
+    ChannelInterleaver il(bps, total);
+    std::vector<float> probe(total);
+    for (int i = 0; i < total; ++i) probe[i] = static_cast<float>(i);
+    auto d = il.deinterleave(std::span<const float>(probe));
+    for (int i = 0; i < total; ++i) inv_out[i] = static_cast<int>(d[i]);  // dec_in[i] = rx[inv_out[i]]
+    return total;
+}
+
+// ---------------------------------------------------------------- sync
+// LTS light sync (ofdm_chirp_waveform.cpp:207-384)
+int ref_detect_data_sync(int mod, int rate, const float* samples, int n, float known_cfo, float thr,
+                         int* start_out, float* corr_out, int* burst_out) {
+    ref_quiet();
+    ModemConfig cfg = named_config(mod, rate);
+    OFDMChirpWaveform rx(cfg);
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    SyncResult r;
+    bool ok = rx.detectDataSync(SampleSpan(samples, n), r, known_cfo, thr);
+    *start_out = r.start_sample;
+    *corr_out = r.correlation;
+    if (burst_out) *burst_out = rx.wasBurstInterleaved() ? 1 : 0;
+    return ok ? 1 : 0;
+}
+
+// Dual chirp (chirp_sync.hpp:352-512); out = {success, up_start, down_start, cfo_hz, up_corr, down_corr}
+int ref_chirp_detect(const float* samples, int n, float thr, float* out6) {
+    ref_quiet();
+    ModemConfig cfg = named_config(static_cast<int>(Modulation::QAM16), static_cast<int>(CodeRate::R1_2));
+    OFDMChirpWaveform w(cfg);
+    auto r = w.chirp_sync_->detectDualChirp(SampleSpan(samples, n), thr);
+    out6[0] = r.success ? 1.f : 0.f;
+    out6[1] = static_cast<float>(r.up_chirp_start);
+    out6[2] = static_cast<float>(r.down_chirp_start);
+    out6[3] = r.cfo_hz;
+    out6[4] = r.up_correlation;
+    out6[5] = r.down_correlation;
+    return r.success ? 1 : 0;
+}
+
+int ref_chirp_generate(float* out, int max_n) {
+    ref_quiet();
+    ModemConfig cfg = named_config(static_cast<int>(Modulation::QAM16), static_cast<int>(CodeRate::R1_2));
+    OFDMChirpWaveform w(cfg);
+    Samples s = w.chirp_sync_->generate();
+    int n = static_cast<int>(s.size());
+    if (n > max_n) return -n;
+    std::memcpy(out, s.data(), n * sizeof(float));
+    return n;
+}
+
+}  // extern "C"
