@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Pin the C restatement (oracle/ria_oracle.c) against the compiled unmodified reference
+(oracle/_ref/libria_ref.so).  Build-container only (needs /root/reference to have been compiled by
+`make -C oracle ref`).  Everything is compared BIT-EXACT (float32 bit patterns, bytes, counters).
+
+Usage: python oracle/check_against_ref.py [--frames N]
+"""
+import argparse
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pyoracle as po  # noqa: E402
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=12)
+    args = ap.parse_args()
+    if not po.Ref.available():
+        print("oracle/_ref/libria_ref.so missing: run `make -C oracle ref` in the build container")
+        return 2
+    O, R = po.Oracle(), po.Ref()
+    rng = np.random.default_rng(2024)
+    fails = 0
+
+    def check(name, cond, extra=""):
+        nonlocal fails
+        print(("PASS " if cond else "FAIL ") + name + (" " + extra if extra else ""))
+        if not cond:
+            fails += 1
+
+    # 1. LDPC encoder, every rate
+    for rate in (po.R1_4, po.R1_3, po.R1_2, po.R2_3, po.R3_4, po.R5_6):
+        k = O.code(rate).k
+        ok = True
+        for _ in range(8):
+            info = rng.integers(0, 256, k // 8, dtype=np.uint8)
+            ok &= np.array_equal(O.ldpc_encode(rate, info), R.ldpc_encode(rate, info)[:81])
+        check(f"ldpc_encode rate={rate} (edges={O.code(rate).n_edges})", ok)
+
+    # 2. channel interleaver permutations
+    for bps in (188, 106, 110, 204, 255, 306, 94, 60, 20, 10):
+        inv = R.channel_interleaver_inv(bps)
+        step = O.lib.ro_channel_interleaver_step(bps, 648)
+        mine = (np.arange(648) * step) % 648
+        check(f"channel_interleaver bps={bps} step={step}", np.array_equal(inv, mine))
+
+    # 3. TX chain + 4. channel + 5. RX + 7. decode, per mode
+    modes = [(po.QAM16, po.R1_2), (po.DQPSK, po.R1_2), (po.QPSK, po.R1_2), (po.QAM64, po.R3_4),
+             (po.QAM32, po.R3_4), (po.QAM16, po.R3_4), (po.DQPSK, po.R1_4), (po.BPSK, po.R1_2),
+             (po.DBPSK, po.R1_4), (po.DQPSK, po.R3_4), (po.QAM16, po.R2_3)]
+    for mod, rate in modes:
+        g = O.geom(mod, rate)
+        cap = 4 * g.bytes_per_cw - 19
+        tx_ok = rx_ok = ch_ok = dec_ok = True
+        n_dec = 0
+        worst = ""
+        for f in range(args.frames):
+            payload = rng.integers(0, 256, cap, dtype=np.uint8)
+            s_ref, info_ref, coded_ref, bps = R.tx_frame(mod, rate, payload, f)
+            s_mine, info_mine, coded_mine = O.tx_frame(mod, rate, payload, f)
+            tx_ok &= (bps == g.bits_per_symbol and np.array_equal(info_ref[:len(info_mine)], info_mine)
+                      and np.array_equal(coded_ref, coded_mine) and bits_equal(s_ref, s_mine))
+            x = s_ref * np.float32(0.8 / np.abs(s_ref).max())
+            kind, snr = [(0, 20.0), (0, 12.0), (2, 20.0), (1, 15.0), (3, 20.0), (4, 25.0)][f % 6]
+            cfo = [0.0, 0.0, 0.0, 2.5, -7.0, 0.4][f % 6]
+            y_ref = R.channel(kind, snr, 1000 + f, x)
+            y_mine = O.channel(kind, snr, 1000 + f, x)
+            ch_ok &= bits_equal(y_ref, y_mine)
+            abs_pos = [0, 0, 12345, 4800, 77, 0][f % 6]
+            llr_ref, aux_ref, h_ref, _ = R.rx_process(mod, rate, y_ref, cfo, abs_pos)
+            llr_mine, aux_mine, = O.rx_process(mod, rate, y_ref, cfo, abs_pos)
+            aux_m = np.array([aux_mine.snr_db, aux_mine.cfo_hz, aux_mine.fading_index, aux_mine.noise_variance,
+                              aux_mine.lts_phase_slope, aux_mine.snr_linear, aux_mine.corr_phase,
+                              aux_mine.snr_symbol_count], np.float32)
+            same = bits_equal(llr_ref, llr_mine) and bits_equal(h_ref, np.array(aux_mine.h, np.float32)) \
+                and bits_equal(aux_ref[1:], aux_m[1:])
+            if not same and not worst:
+                nd = int(np.sum(llr_ref.view(np.uint32) != llr_mine.view(np.uint32))) if len(llr_ref) == len(llr_mine) else -1
+                worst = f"[frame {f} kind={kind} cfo={cfo}: {nd} LLRs differ, aux ref={aux_ref} mine={aux_m}]"
+            rx_ok &= same
+            d_ref, ok_ref = R.decode_fixed_frame(llr_ref, rate, True, g.bits_per_symbol)
+            d_mine, ok_mine, iters, att = O.decode_fixed_frame(llr_ref, rate, True, g.bits_per_symbol, flags=7)
+            same = np.array_equal(ok_ref, ok_mine) and np.array_equal(d_ref[:len(d_mine)], d_mine)
+            dec_ok &= same
+            n_dec += int(ok_ref.all())
+        check(f"tx        mod={mod} rate={rate}", tx_ok)
+        check(f"channel   mod={mod} rate={rate}", ch_ok)
+        check(f"rx llr    mod={mod} rate={rate}", rx_ok, worst)
+        check(f"decode    mod={mod} rate={rate} ({n_dec}/{args.frames} frames fully decoded by ref)", dec_ok)
+
+    # 6. raw LDPC decode incl. iteration counts, noisy codewords around the waterfall
+    for rate in (po.R1_4, po.R1_2, po.R2_3, po.R3_4, po.R5_6):
+        c = O.code(rate)
+        ok = True
+        n_succ = 0
+        for t in range(40):
+            info = rng.integers(0, 256, (c.k + 7) // 8, dtype=np.uint8)
+            cw = np.unpackbits(O.ldpc_encode(rate, info))[:648].astype(np.float32)
+            sigma = [0.5, 0.7, 0.8, 0.9, 1.0][t % 5] * (1.3 if rate == po.R1_4 else 1.0)
+            llr = (2.0 * (1.0 - 2.0 * cw) + rng.normal(0, 2.0 * sigma, 648)).astype(np.float32) * np.float32(2.0 / (2 * sigma) ** 2)
+            for factor, mi in ((0.9375, 80), (0.75, 50)):
+                ok_r, out_r, it_r = R.ldpc_decode(rate, llr, mi, factor)
+                ok_m, out_m, it_m = O.ldpc_decode(rate, llr, mi, factor)
+                ok &= (ok_r == ok_m and it_r == it_m and np.array_equal(out_r, out_m))
+                n_succ += ok_r
+        check(f"ldpc_decode rate={rate} ({n_succ}/80 converged)", ok)
+
+    print("\n%s: %d failing group(s)" % ("PINNED" if fails == 0 else "MISMATCH", fails))
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

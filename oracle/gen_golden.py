@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the compiled unmodified reference (oracle/_ref/libria_ref.so).
+
+Build-container only.  The fixtures are DATA (inputs and the reference's outputs at each stage tap);
+no reference source travels.  Re-run after `make -C oracle ref`:
+
+    python oracle/gen_golden.py
+
+Stage taps per frame: payload -> frame info bytes -> interleaved coded bytes
+-> TX samples -> channel output -> LLRs (+ estimator state: H[59], noise variance, phase slope,
+CFO, fading index) -> decodeFixedFrame status and bytes.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pyoracle as po  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(po.HERE), "tests", "golden")
+
+# (name, mod, rate, [(channel kind, snr_db, cfo_hz, abs_pos)], keep_tx)
+FRAME_SETS = [
+    ("qam16_r12", po.QAM16, po.R1_2,
+     [(0, 20.0, 0.0, 0), (0, 12.0, 0.0, 0), (2, 20.0, 0.0, 0), (2, 20.0, 0.0, 0), (2, 15.0, 0.0, 0),
+      (1, 15.0, 2.5, 4800), (3, 20.0, -7.0, 12345), (0, 25.0, 0.4, 0), (2, 25.0, 0.0, 0), (4, 25.0, 0.0, 0)]),
+    ("dqpsk_r12", po.DQPSK, po.R1_2,
+     [(0, 20.0, 0.0, 0), (0, 10.0, 0.0, 0), (2, 20.0, 0.0, 0), (1, 15.0, 3.0, 960)]),
+    ("qam64_r34", po.QAM64, po.R3_4, [(0, 30.0, 0.0, 0), (0, 24.0, 0.0, 0), (1, 30.0, 0.0, 0)]),
+    ("qam32_r34", po.QAM32, po.R3_4, [(0, 28.0, 0.0, 0), (1, 25.0, 0.0, 0)]),
+    ("qpsk_r12", po.QPSK, po.R1_2, [(0, 12.0, 0.0, 0), (2, 15.0, 0.0, 0)]),
+    ("dqpsk_r14", po.DQPSK, po.R1_4, [(0, 6.0, 0.0, 0), (3, 10.0, 0.0, 0)]),
+    ("qam16_r34", po.QAM16, po.R3_4, [(0, 22.0, 0.0, 0), (2, 25.0, 0.0, 0)]),
+]
+
+
+def main():
+    if not po.Ref.available():
+        print("needs oracle/_ref/libria_ref.so (make -C oracle ref)")
+        return 2
+    os.makedirs(OUT, exist_ok=True)
+    R = po.Ref()
+    rng = np.random.default_rng(20261004)
+
+    # ---- frames
+    for name, mod, rate, chans in FRAME_SETS:
+        rec = {}
+        bytes_per_cw = {po.R1_4: 20, po.R1_2: 40, po.R2_3: 54, po.R3_4: 60, po.R5_6: 67}[rate]
+        cap = 4 * bytes_per_cw - 19
+        rec["mod"], rec["rate"] = np.int32(mod), np.int32(rate)
+        L = {k: [] for k in ("payload", "info", "coded", "tx", "rx", "llr", "aux", "h", "dec_data", "dec_ok",
+                             "chan", "seq")}
+        for f, (kind, snr, cfo, abs_pos) in enumerate(chans):
+            payload = rng.integers(0, 256, cap, dtype=np.uint8)
+            seq = 100 + f
+            s, info, coded, bps = R.tx_frame(mod, rate, payload, seq)
+            x = s * np.float32(0.8 / np.abs(s).max())  # tools/test_waveform_simple.cpp:365-371
+            y = R.channel(kind, snr, 4242 + f, x)
+            llr, aux, h, _ = R.rx_process(mod, rate, y, cfo, abs_pos)
+            d, ok = R.decode_fixed_frame(llr, rate, True, bps)
+            L["payload"].append(payload); L["info"].append(info[:4 * bytes_per_cw]); L["coded"].append(coded)
+            L["tx"].append(s if f < 2 else np.zeros(0, np.float32))
+            L["rx"].append(y); L["llr"].append(llr); L["aux"].append(aux); L["h"].append(h)
+            L["dec_data"].append(d[:4 * bytes_per_cw]); L["dec_ok"].append(ok)
+            L["chan"].append(np.array([kind, snr, cfo, abs_pos, 4242 + f], np.float64)); L["seq"].append(seq)
+        rec["bps"] = np.int32(bps)
+        rec["tx0"], rec["tx1"] = L["tx"][0], L["tx"][1]
+        for k in ("payload", "info", "coded", "rx", "llr", "aux", "h", "dec_data", "dec_ok", "chan"):
+            rec[k] = np.stack(L[k])
+        rec["seq"] = np.array(L["seq"], np.int32)
+        np.savez_compressed(os.path.join(OUT, f"frames_{name}.npz"), **rec)
+        print(name, "frames", len(chans), "decoded", [int(o.all()) for o in L["dec_ok"]])
+
+    # ---- raw LDPC vectors per rate (encode + decode with iteration counts)
+    rec = {}
+    for rate in (po.R1_4, po.R1_2, po.R2_3, po.R3_4, po.R5_6):
+        k = {po.R1_4: 162, po.R1_2: 324, po.R2_3: 432, po.R3_4: 486, po.R5_6: 540}[rate]
+        infos, cws, llrs, res = [], [], [], []
+        for t in range(24):
+            info = rng.integers(0, 256, (k + 7) // 8, dtype=np.uint8)
+            if k % 8:
+                info[-1] &= (0xFF << (8 - k % 8)) & 0xFF
+            cw = R.ldpc_encode(rate, info)[:81]
+            bits = np.unpackbits(cw)[:648].astype(np.float32)
+            sigma = [0.45, 0.6, 0.7, 0.8, 0.9, 1.0][t % 6] * (1.4 if rate == po.R1_4 else 1.0) * (0.75 if rate >= po.R3_4 else 1.0)
+            llr = ((1.0 - 2.0 * bits) + rng.normal(0, sigma, 648)) * (2.0 / sigma ** 2)
+            llr = np.clip(llr, -20, 20).astype(np.float32)
+            row = []
+            for factor, mi in ((0.9375, 80), (0.75, 50), (0.5, 80)):
+                ok, out, it = R.ldpc_decode(rate, llr, mi, factor)
+                row.append(np.concatenate([[int(ok), it], out[:(k + 7) // 8]]).astype(np.int32))
+            infos.append(info); cws.append(cw); llrs.append(llr); res.append(np.stack(row))
+        rec[f"info_{rate}"] = np.stack(infos)
+        rec[f"cw_{rate}"] = np.stack(cws)
+        rec[f"llr_{rate}"] = np.stack(llrs)
+        rec[f"res_{rate}"] = np.stack(res)  # [t, 3 configs, 2 + nbytes]
+    rec["configs"] = np.array([[0.9375, 80], [0.75, 50], [0.5, 80]], np.float32)
+    np.savez_compressed(os.path.join(OUT, "ldpc_vectors.npz"), **rec)
+    print("ldpc vectors written")
+
+    # ---- channel interleaver permutations
+    rec = {}
+    for bps in (188, 106, 110, 204, 255, 306, 94, 60, 20, 10):
+        rec[f"inv_{bps}"] = R.channel_interleaver_inv(bps)
+    np.savez_compressed(os.path.join(OUT, "channel_interleaver.npz"), **rec)
+
+    # ---- channel model output (bit-exact restatement target) on a short deterministic input
+    t = np.arange(6000, dtype=np.float32)
+    x = (0.3 * np.sin(2 * np.pi * 1500.0 * t / 48000.0)).astype(np.float32)
+    x[:200] = 0
+    rec = {"x": x}
+    for kind in range(5):
+        rec[f"y_{kind}"] = R.channel(kind, 15.0, 77 + kind, x)
+    np.savez_compressed(os.path.join(OUT, "channel_vectors.npz"), **rec)
+    print("done ->", OUT)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,258 @@
+"""ctypes bindings for the CPU checkers.  TEST INFRASTRUCTURE ONLY.
+
+`Oracle`  -> oracle/libria_oracle.so  (our C restatement, travels everywhere)
+`Ref`     -> oracle/_ref/libria_ref.so (the compiled unmodified reference; build container only)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+DBPSK, BPSK, DQPSK, QPSK, D8PSK, QAM8, QAM16, QAM32, QAM64, QAM256 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 10
+R1_4, R1_3, R1_2, R2_3, R3_4, R5_6, R7_8 = range(7)
+NCAR, CW_BITS, FRAME_BITS, MAX_EDGES = 59, 648, 2592, 4096
+
+_f = C.POINTER(C.c_float)
+_u8 = C.POINTER(C.c_uint8)
+_i = C.POINTER(C.c_int)
+
+
+def fp(a):
+    return a.ctypes.data_as(_f)
+
+
+def up(a):
+    return a.ctypes.data_as(_u8)
+
+
+def ip(a):
+    return a.ctypes.data_as(_i)
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "mod", "rate", "pilot_spacing", "n_pilot", "n_data", "bits_per_carrier", "bits_per_symbol",
+        "n_data_symbols", "frame_samples", "n_llr", "info_bits", "bytes_per_cw", "max_iter")] + [
+        ("all_idx", C.c_int * NCAR), ("is_pilot", C.c_int * NCAR),
+        ("data_idx", C.c_int * NCAR), ("pilot_idx", C.c_int * NCAR),
+        ("data_logical", C.c_int * NCAR), ("pilot_logical", C.c_int * NCAR),
+        ("sync_re", C.c_float * NCAR), ("sync_im", C.c_float * NCAR),
+        ("pilot_seq", C.c_float * NCAR),
+        ("interp_lo", C.c_int * NCAR), ("interp_hi", C.c_int * NCAR),
+        ("interp_alpha", C.c_float * NCAR)]
+
+
+class Ldpc(C.Structure):
+    _fields_ = [("rate", C.c_int), ("k", C.c_int), ("m", C.c_int), ("n", C.c_int), ("n_edges", C.c_int),
+                ("row_ptr", C.c_int * (CW_BITS + 1)), ("edge_var", C.c_int * MAX_EDGES)]
+
+
+class RxAux(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "snr_db", "cfo_hz", "fading_index", "noise_variance", "lts_phase_slope", "snr_linear",
+        "corr_phase", "snr_symbol_count")] + [("h", C.c_float * (2 * NCAR))]
+
+
+def build_oracle():
+    so = os.path.join(HERE, "libria_oracle.so")
+    src = os.path.join(HERE, "ria_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    return so
+
+
+class Oracle:
+    """Our C restatement (oracle/ria_oracle.c)."""
+
+    def __init__(self):
+        self.lib = L = C.CDLL(build_oracle())
+        L.ro_rx_process.argtypes = [C.POINTER(Geom), _f, C.c_int, C.c_float, C.c_longlong, _f, C.c_int,
+                                    C.POINTER(RxAux)]
+        L.ro_channel.argtypes = [C.c_int, C.c_float, C.c_uint32, _f, C.c_int, _f]
+        L.ro_ldpc_decode.argtypes = [C.POINTER(Ldpc), _f, C.c_int, C.c_int, C.c_float, _u8, _i]
+        L.ro_decode_fixed_frame.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8, _u8, _i, _i]
+        L.ro_crc16.restype = C.c_uint16
+        self._geoms = {}
+        self._codes = {}
+
+    def geom(self, mod, rate):
+        key = (mod, rate)
+        if key not in self._geoms:
+            g = Geom()
+            self.lib.ro_geom_init(C.byref(g), mod, rate)
+            self._geoms[key] = g
+        return self._geoms[key]
+
+    def code(self, rate):
+        if rate not in self._codes:
+            c = Ldpc()
+            self.lib.ro_ldpc_build(C.byref(c), rate)
+            self._codes[rate] = c
+        return self._codes[rate]
+
+    def H_edges(self, rate):
+        c = self.code(rate)
+        return (np.array(c.row_ptr[:c.m + 1], dtype=np.int32),
+                np.array(c.edge_var[:c.n_edges], dtype=np.int32), c.k, c.m)
+
+    def make_frame(self, payload, seq, rate):
+        g = self.geom(QAM16, rate)
+        out = np.zeros(4 * g.bytes_per_cw, np.uint8)
+        payload = np.ascontiguousarray(payload, np.uint8)
+        self.lib.ro_make_frame(up(payload), len(payload), seq, rate, up(out))
+        return out
+
+    def encode_fixed_frame(self, info, rate, ch_il, bps):
+        info = np.ascontiguousarray(info, np.uint8)
+        out = np.zeros(324, np.uint8)
+        self.lib.ro_encode_fixed_frame(up(info), len(info), rate, int(ch_il), bps, up(out))
+        return out
+
+    def modulate(self, mod, rate, coded):
+        g = self.geom(mod, rate)
+        coded = np.ascontiguousarray(coded, np.uint8)
+        out = np.zeros(g.frame_samples + 1152, np.float32)
+        n = self.lib.ro_modulate(C.byref(g), up(coded), len(coded), fp(out), len(out))
+        assert n > 0
+        return out[:n].copy()
+
+    def tx_frame(self, mod, rate, payload, seq):
+        g = self.geom(mod, rate)
+        info = self.make_frame(payload, seq, rate)
+        coded = self.encode_fixed_frame(info, rate, True, g.bits_per_symbol)
+        return self.modulate(mod, rate, coded), info, coded
+
+    def channel(self, kind, snr_db, seed, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        self.lib.ro_channel(kind, snr_db, seed, fp(x), len(x), fp(y))
+        return y
+
+    def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0):
+        g = self.geom(mod, rate)
+        samples = np.ascontiguousarray(samples, np.float32)
+        llr = np.zeros(8 * NCAR * 64, np.float32)
+        aux = RxAux()
+        n = self.lib.ro_rx_process(C.byref(g), fp(samples), len(samples), cfo_hz, abs_pos, fp(llr), len(llr),
+                                   C.byref(aux))
+        return llr[:n].copy(), aux
+
+    def ldpc_encode(self, rate, info):
+        c = self.code(rate)
+        info = np.ascontiguousarray(info, np.uint8)
+        out = np.zeros(81, np.uint8)
+        self.lib.ro_ldpc_encode(C.byref(c), up(info), len(info), up(out))
+        return out
+
+    def ldpc_decode(self, rate, llr, max_iter, factor):
+        c = self.code(rate)
+        llr = np.ascontiguousarray(llr, np.float32)
+        out = np.zeros(81, np.uint8)
+        it = C.c_int()
+        ok = self.lib.ro_ldpc_decode(C.byref(c), fp(llr), len(llr), max_iter, factor, up(out), C.byref(it))
+        return bool(ok), out[:(c.k + 7) // 8].copy(), it.value
+
+    def decode_fixed_frame(self, llr, rate, ch_deint, bps, flags=3):
+        g = self.geom(QAM16, rate)
+        llr = np.ascontiguousarray(llr, np.float32)
+        data = np.zeros(4 * g.bytes_per_cw, np.uint8)
+        ok = np.zeros(4, np.uint8)
+        iters = np.zeros(4, np.int32)
+        att = np.zeros(4, np.int32)
+        self.lib.ro_decode_fixed_frame(fp(llr), len(llr), rate, int(ch_deint), bps, flags, up(data), up(ok),
+                                       ip(iters), ip(att))
+        return data, ok, iters, att
+
+    def gather_table(self, bps, use_channel=True):
+        t = np.zeros(4 * CW_BITS, np.int32)
+        self.lib.ro_rx_gather_table(bps, int(use_channel), ip(t))
+        return t
+
+
+class Ref:
+    """The compiled, unmodified reference (oracle/_ref/libria_ref.so). Build container only."""
+
+    PATH = os.path.join(HERE, "_ref", "libria_ref.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        self.lib = L = C.CDLL(self.PATH)
+        L.ref_channel.argtypes = [C.c_int, C.c_float, C.c_uint32, _f, C.c_int, _f]
+        L.ref_rx_process.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_longlong, C.c_int, _f,
+                                     C.c_int, _f, _f]
+        L.ref_ldpc_decode.argtypes = [C.c_int, _f, C.c_int, C.c_int, C.c_float, _u8, C.c_int, _i]
+        L.ref_detect_data_sync.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _i, _f, _i]
+        L.ref_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
+        L.ref_quiet()
+
+    def tx_frame(self, mod, rate, payload, seq):
+        payload = np.ascontiguousarray(payload, np.uint8)
+        samples = np.zeros(80000, np.float32)
+        info = np.zeros(4 * 68, np.uint8)
+        coded = np.zeros(324, np.uint8)
+        bps = C.c_int()
+        n = self.lib.ref_tx_frame(mod, rate, up(payload), len(payload), seq, fp(samples), len(samples),
+                                  up(info), len(info), up(coded), 324, C.byref(bps))
+        assert n > 0
+        return samples[:n].copy(), info, coded, bps.value
+
+    def encode_fixed_frame(self, info, rate, ch_il, bps):
+        info = np.ascontiguousarray(info, np.uint8)
+        out = np.zeros(324, np.uint8)
+        self.lib.ref_encode_fixed_frame(up(info), len(info), rate, int(ch_il), bps, up(out), 324)
+        return out
+
+    def modulate(self, mod, rate, coded):
+        coded = np.ascontiguousarray(coded, np.uint8)
+        out = np.zeros(80000, np.float32)
+        n = self.lib.ref_modulate(mod, rate, up(coded), len(coded), fp(out), len(out))
+        assert n > 0
+        return out[:n].copy()
+
+    def channel(self, kind, snr_db, seed, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        self.lib.ref_channel(kind, snr_db, seed, fp(x), len(x), fp(y))
+        return y
+
+    def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0, use_abs=True):
+        samples = np.ascontiguousarray(samples, np.float32)
+        llr = np.zeros(8 * NCAR * 64, np.float32)
+        aux = np.zeros(8, np.float32)
+        h = np.zeros(2 * NCAR, np.float32)
+        n = self.lib.ref_rx_process(mod, rate, fp(samples), len(samples), cfo_hz, abs_pos, int(use_abs),
+                                    fp(llr), len(llr), fp(aux), fp(h))
+        return llr[:abs(n)].copy(), aux, h, n > 0
+
+    def ldpc_encode(self, rate, info):
+        info = np.ascontiguousarray(info, np.uint8)
+        out = np.zeros(256, np.uint8)
+        n = self.lib.ref_ldpc_encode(rate, up(info), len(info), up(out), 256)
+        return out[:n].copy()
+
+    def ldpc_decode(self, rate, llr, max_iter, factor):
+        llr = np.ascontiguousarray(llr, np.float32)
+        out = np.zeros(256, np.uint8)
+        it = C.c_int()
+        n = self.lib.ref_ldpc_decode(rate, fp(llr), len(llr), max_iter, factor, up(out), 256, C.byref(it))
+        return n > 0, out[:abs(n)].copy(), it.value
+
+    def decode_fixed_frame(self, llr, rate, ch_deint, bps):
+        llr = np.ascontiguousarray(llr, np.float32)
+        data = np.zeros(4 * 68, np.uint8)
+        ok = np.zeros(4, np.uint8)
+        self.lib.ref_decode_fixed_frame(fp(llr), len(llr), rate, int(ch_deint), bps, up(data), up(ok))
+        return data, ok
+
+    def channel_interleaver_inv(self, bps, total=648):
+        out = np.zeros(total, np.int32)
+        self.lib.ref_channel_interleaver_perm(bps, total, ip(out))
+        return out

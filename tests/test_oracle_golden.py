@@ -1,0 +1,114 @@
+"""CPU: the C restatement (oracle/) must reproduce, bit for bit, the golden vectors that
+oracle/gen_golden.py recorded from the compiled unmodified reference.
+Mirrors what the reference's tool executables check (test_waveform_simple: TX -> channel -> RX ->
+decoded set; test_chase_cache-style exact arithmetic), but at every stage tap."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+FRAME_SETS = ["qam16_r12", "dqpsk_r12", "qam64_r34", "qam32_r34", "qpsk_r12", "dqpsk_r14", "qam16_r34"]
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", FRAME_SETS)
+def test_tx_chain_matches_reference(oracle, golden, name):
+    g = golden("frames_" + name)
+    mod, rate = int(g["mod"]), int(g["rate"])
+    for f in range(len(g["payload"])):
+        s, info, coded = oracle.tx_frame(mod, rate, g["payload"][f], int(g["seq"][f]))
+        assert np.array_equal(info, g["info"][f])
+        assert np.array_equal(coded, g["coded"][f])
+        if f < 2:
+            assert bits_equal(s, g["tx%d" % f]), "TX samples differ from the reference"
+
+
+@pytest.mark.parametrize("name", FRAME_SETS)
+def test_rx_llrs_bit_exact(oracle, golden, name):
+    g = golden("frames_" + name)
+    mod, rate = int(g["mod"]), int(g["rate"])
+    for f in range(len(g["rx"])):
+        kind, snr, cfo, abs_pos, seed = g["chan"][f]
+        llr, aux = oracle.rx_process(mod, rate, g["rx"][f], float(cfo), int(abs_pos))
+        assert bits_equal(llr, g["llr"][f]), f"frame {f}: LLRs differ"
+        assert bits_equal(np.array(aux.h, np.float32), g["h"][f])
+        mine = np.array([aux.cfo_hz, aux.fading_index, aux.noise_variance, aux.lts_phase_slope, aux.snr_linear,
+                         aux.corr_phase, aux.snr_symbol_count], np.float32)
+        assert bits_equal(mine, g["aux"][f][1:])
+
+
+@pytest.mark.parametrize("name", FRAME_SETS)
+def test_decode_fixed_frame_matches_reference(oracle, golden, name):
+    g = golden("frames_" + name)
+    rate, bps = int(g["rate"]), int(g["bps"])
+    for f in range(len(g["llr"])):
+        data, ok, iters, att = oracle.decode_fixed_frame(g["llr"][f], rate, True, bps, flags=7)
+        assert np.array_equal(ok, g["dec_ok"][f]), f"frame {f}: status {ok} vs {g['dec_ok'][f]}"
+        assert np.array_equal(data, g["dec_data"][f])
+        if g["dec_ok"][f].all() and name != "qam64_r34" and name != "qam32_r34" and name != "qam16_r34":
+            # R1/4..R1/2 codes: a decoded frame is the transmitted frame
+            assert np.array_equal(data, g["info"][f])
+
+
+def test_channel_model_bit_exact(oracle, golden):
+    g = golden("channel_vectors")
+    for kind in range(5):
+        y = oracle.channel(kind, 15.0, 77 + kind, g["x"])
+        assert bits_equal(y, g[f"y_{kind}"]), f"channel kind {kind}"
+
+
+def test_channel_on_frames_bit_exact(oracle, golden):
+    g = golden("frames_qam16_r12")
+    for f in range(2):
+        s = g["tx%d" % f]
+        x = s * np.float32(0.8 / np.abs(s).max())
+        kind, snr, cfo, abs_pos, seed = g["chan"][f]
+        assert bits_equal(oracle.channel(int(kind), float(snr), int(seed), x), g["rx"][f])
+
+
+def test_ldpc_vectors(oracle, golden):
+    g = golden("ldpc_vectors")
+    cfgs = g["configs"]
+    for rate in (po.R1_4, po.R1_2, po.R2_3, po.R3_4, po.R5_6):
+        k = oracle.code(rate).k
+        nb = (k + 7) // 8
+        for t in range(len(g[f"info_{rate}"])):
+            assert np.array_equal(oracle.ldpc_encode(rate, g[f"info_{rate}"][t]), g[f"cw_{rate}"][t])
+            for c, (factor, mi) in enumerate(cfgs):
+                ok, out, it = oracle.ldpc_decode(rate, g[f"llr_{rate}"][t], int(mi), float(factor))
+                ref = g[f"res_{rate}"][t, c]
+                assert (int(ok), it) == (int(ref[0]), int(ref[1]))
+                assert np.array_equal(out, ref[2:2 + nb].astype(np.uint8))
+
+
+def test_ldpc_degree_profile(oracle):
+    """1623 edges at R1/2, row degree 2..7, info column degree 4..5."""
+    row_ptr, edge_var, k, m = oracle.H_edges(po.R1_2)
+    assert len(edge_var) == 1623 and (k, m) == (324, 324)
+    deg = np.diff(row_ptr)
+    assert deg.min() >= 2 and deg.max() <= 7
+    col = np.bincount(edge_var, minlength=648)
+    assert set(col[:324]) <= {4, 5} and (col[324:] == 1).all()
+    assert [len(oracle.H_edges(r)[1]) for r in (po.R1_4, po.R2_3, po.R3_4, po.R5_6)] == [2437, 1510, 1134, 756]
+
+
+def test_channel_interleaver_tables(oracle, golden):
+    g = golden("channel_interleaver")
+    for bps in (188, 106, 110, 204, 255, 306, 94, 60, 20, 10):
+        step = oracle.lib.ro_channel_interleaver_step(bps, 648)
+        assert np.array_equal((np.arange(648) * step) % 648, g[f"inv_{bps}"])
+    assert oracle.lib.ro_channel_interleaver_step(188, 648) == 565
+
+
+def test_frame_geometry_named_shape(oracle):
+    """18 432 samples in, 2 632 LLRs, 12 pilots / 47 data carriers, 188 bits/symbol."""
+    g = oracle.geom(po.QAM16, po.R1_2)
+    assert (g.n_pilot, g.n_data, g.bits_per_symbol, g.n_data_symbols, g.frame_samples, g.n_llr) == \
+        (12, 47, 188, 14, 18432, 2632)
+    g = oracle.geom(po.DQPSK, po.R1_2)
+    assert (g.n_pilot, g.n_data, g.bits_per_symbol, g.frame_samples, g.n_llr) == (6, 53, 106, 31104, 2650)
