@@ -1,0 +1,190 @@
+/* include/ria_gpu.h — C ABI of libria_gpu.so: the MI355X (gfx950) RX signal chain for the RIA modem.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one call the unmodified
+ * host code (gui::StreamingDecoder, tools/cli_simulator, tools/test_waveform_simple) makes today;
+ * the reference interface each one stands in for is cited as file:line relative to the reference
+ * repository.  INTEGRATION.md shows the adaptor class a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C, no exceptions: every function returns RIA_OK (0) or a negative ria_status; the text
+ *     of the last error of a handle is available from ria_gpu_last_error().
+ *   - "dev" pointers are device (HBM) addresses valid on the handle's GPU; "host" variants copy
+ *     over PCIe themselves.  `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     device-pointer calls are asynchronous on that stream, host-pointer calls return when done.
+ *   - a handle is bound to one (modulation, code rate) pair like one configured IWaveform object
+ *     (waveform_interface.hpp:69 configure()); it is not thread-safe, like the reference
+ *     (streaming_decoder.cpp:719 holds waveform_mutex_ around every call).
+ *   - enum values are the reference's own (include/ultra/types.hpp:28-39, :91-100).
+ */
+#ifndef RIA_GPU_H
+#define RIA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIA_GPU_ABI_VERSION 1
+
+typedef enum ria_status {
+    RIA_OK = 0,
+    RIA_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    RIA_ERR_NO_DEVICE = -2,    /* no gfx950 device or HIP runtime failure at create */
+    RIA_ERR_HIP = -3,          /* a HIP call failed (see ria_gpu_last_error) */
+    RIA_ERR_UNSUPPORTED = -4   /* valid request this build does not implement yet */
+} ria_status;
+
+/* Modulation (types.hpp:28-39) and CodeRate (types.hpp:91-100) */
+enum { RIA_MOD_DBPSK = 0, RIA_MOD_BPSK = 1, RIA_MOD_DQPSK = 2, RIA_MOD_QPSK = 3, RIA_MOD_D8PSK = 4,
+       RIA_MOD_QAM16 = 6, RIA_MOD_QAM32 = 7, RIA_MOD_QAM64 = 8, RIA_MOD_QAM256 = 10 };
+enum { RIA_RATE_1_4 = 0, RIA_RATE_1_3 = 1, RIA_RATE_1_2 = 2, RIA_RATE_2_3 = 3, RIA_RATE_3_4 = 4,
+       RIA_RATE_5_6 = 5 };
+
+/* Immutable per-handle configuration: the subset of ultra::ModemConfig (types.hpp:193-289) the
+ * OFDM-CHIRP RX path reads.  Zero-initialise, then ria_gpu_default_config(). */
+typedef struct ria_gpu_config {
+    int32_t abi_version;     /* RIA_GPU_ABI_VERSION */
+    int32_t device;          /* HIP device ordinal */
+    int32_t modulation;      /* RIA_MOD_* */
+    int32_t code_rate;       /* RIA_RATE_* */
+    int32_t fft_size;        /* 1024 */
+    int32_t num_carriers;    /* 59 */
+    int32_t cyclic_prefix;   /* 128 (CyclicPrefixMode::LONG at FFT 1024) */
+    int32_t sample_rate;     /* 48000 */
+    int32_t center_freq;     /* 1500 */
+    int32_t max_batch;       /* frames per call the workspace is sized for */
+    int32_t reserved[6];
+} ria_gpu_config;
+
+/* Frame geometry derived from the configuration (ofdm_chirp_waveform.cpp:616-648,
+ * ofdm_link_adaptation.hpp:26-70, frame_v2.hpp:671-691). */
+typedef struct ria_gpu_geometry {
+    int32_t pilot_spacing, n_pilots, n_data_carriers;
+    int32_t bits_per_carrier, bits_per_symbol;
+    int32_t n_data_symbols;      /* data symbols in a fixed 4-codeword frame */
+    int32_t samples_per_symbol;  /* 1152 */
+    int32_t frame_samples;       /* (2 LTS + n_data_symbols) * 1152 = 18432 for QAM16 R1/2 */
+    int32_t llrs_per_frame;      /* n_data_symbols * bits_per_symbol = 2632 */
+    int32_t info_bits, bytes_per_codeword, info_bytes_per_frame; /* 324, 40, 160 */
+    int32_t ldpc_max_iterations; /* ldpc_codec.hpp:86-95 */
+    int32_t ldpc_edges;
+    int32_t reserved[2];
+} ria_gpu_geometry;
+
+/* Per-frame input of the demodulator: the three setters the host calls before process()
+ * (streaming_decoder.cpp:896 setAbsoluteTrainingPosition, :1347 setFrequencyOffset). */
+typedef struct ria_frame_meta {
+    float    cfo_hz;          /* IWaveform::setFrequencyOffset */
+    uint32_t flags;           /* bit0: first LTS symbol is negated (burst marker, ofdm_chirp_waveform.cpp:421-440) */
+    uint64_t abs_position;    /* IWaveform::setAbsoluteTrainingPosition */
+} ria_frame_meta;
+
+/* Per-frame output of the demodulator: what the host reads back through IWaveform
+ * (estimatedSNR :151, estimatedCFO :154, getFadingIndex :159) plus estimator taps for parity tests. */
+typedef struct ria_frame_status {
+    float snr_db;            /* OFDMDemodulator::getEstimatedSNR */
+    float cfo_hz;            /* corrected CFO fed back to the waveform (ofdm_chirp_waveform.cpp:457-464) */
+    float fading_index;      /* last_fading_index */
+    float noise_variance;    /* LTS noise variance */
+    float lts_phase_slope;
+    float snr_linear;
+    float corr_phase;        /* freq_correction_phase after the last sample */
+    int32_t n_llr;           /* soft bits produced (0 if process() would have returned false) */
+} ria_frame_status;
+
+/* Per-frame output of decodeFixedFrame (frame_v2.hpp:637-664 CodewordStatus). */
+typedef struct ria_decode_status {
+    uint8_t  cw_ok[4];        /* CodewordStatus::decoded */
+    uint16_t iterations[4];   /* LDPCDecoder::lastIterations() of the accepted (or last) attempt */
+    uint8_t  attempts[4];     /* 1 = first decode, 2..5 phase 0, 6.. retry phases 1-6 */
+    uint8_t  frame_valid;     /* 1: header+frame CRC verified on the reassembled frame */
+    uint8_t  needs_recovery;  /* 1: all codewords converged but the frame CRC failed (LDPC false
+                                 positive, frame_v2.cpp:1564-1880): ria_gpu_decode_* finishes it */
+    uint8_t  reserved[2];
+} ria_decode_status;
+
+/* decode flags */
+#define RIA_DECODE_PHASE0      0x1u  /* min-sum factor diversity retries   (frame_v2.cpp:1398-1413) */
+#define RIA_DECODE_PERTURB     0x2u  /* stochastic retry phases 1-6        (frame_v2.cpp:1415-1546) */
+#define RIA_DECODE_CRC_RECOVER 0x4u  /* CRC-guided false-positive recovery (frame_v2.cpp:1564-1880) */
+#define RIA_DECODE_FULL        0x7u  /* exactly v2::decodeFixedFrame */
+#define RIA_DECODE_NO_CHANNEL_DEINTERLEAVE 0x100u
+
+typedef struct ria_gpu* ria_gpu_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int  ria_gpu_abi_version(void);
+void ria_gpu_default_config(ria_gpu_config* cfg);
+/* replaces: std::make_unique<OFDMChirpWaveform>(config) + configure(mod, rate)
+ * (streaming_decoder.cpp:2299,2328; ofdm_chirp_waveform.cpp:81-107) */
+int  ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out);
+void ria_gpu_destroy(ria_gpu_handle h);
+const char* ria_gpu_last_error(ria_gpu_handle h);
+int  ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out);
+
+/* ---- RX: demodulate  (IWaveform::process + getSoftBits, waveform_interface.hpp:124,135;
+ *          OFDMChirpWaveform::process ofdm_chirp_waveform.cpp:391-468) ------------------------- */
+/* samples_dev: frame f starts at samples_dev + (frame_offsets_dev ? frame_offsets_dev[f] : f*frame_samples)
+ * and must hold frame_samples floats from the first LTS sample on.  meta_dev may be NULL (cfo 0).
+ * llr_out_dev: n_frames * llrs_per_frame floats.  status_dev may be NULL. */
+int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
+                        const ria_frame_meta* meta_dev, int n_frames,
+                        float* llr_out_dev, ria_frame_status* status_dev, void* stream);
+
+/* ---- RX: decode  (protocol::v2::decodeFixedFrame, frame_v2.hpp:848, frame_v2.cpp:1335-1883) --- */
+/* llr_dev: frame f at llr_dev + f*llr_stride (first 2592 used).  info_out_dev: n_frames *
+ * info_bytes_per_frame.  status_dev: n_frames entries. */
+int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames,
+                         uint32_t flags, uint8_t* info_out_dev, ria_decode_status* status_dev, void* stream);
+
+/* Single-codeword decoder (LDPCDecoder::decodeSoft, include/ultra/fec.hpp:48-81): n_cw rows of 648
+ * LLRs already in decoder order; out: n_cw * ceil(k/8) bytes; ok/iters: n_cw entries. */
+int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, int max_iterations,
+                              float min_sum_factor, uint8_t* out_dev, uint8_t* ok_dev,
+                              uint16_t* iters_dev, void* stream);
+
+/* ---- RX: fused samples -> payload (process + getSoftBits + decodeFixedFrame in one pass) ------ */
+/* llr_out_dev and demod_status_dev may be NULL. */
+int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
+                     const ria_frame_meta* meta_dev, int n_frames, uint32_t flags,
+                     uint8_t* info_out_dev, ria_decode_status* decode_status_dev,
+                     float* llr_out_dev, ria_frame_status* demod_status_dev, void* stream);
+
+/* Host-buffer convenience for the single-frame IWaveform adaptor (n_frames small). */
+int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ria_frame_meta* meta_host,
+                           int n_frames, uint32_t flags, uint8_t* info_out_host,
+                           ria_decode_status* decode_status_host, float* llr_out_host,
+                           ria_frame_status* demod_status_host);
+
+/* ---- TX synthesis for Monte-Carlo sweeps (v2::encodeFixedFrame frame_v2.cpp:1285-1328 +
+ *      OFDMModulator::generateTrainingSymbols/modulate modulator.cpp:534-583, :348-477) ---------- */
+/* info_dev: n_frames * info_bytes_per_frame (already serialized frames, zero padded);
+ * samples_out_dev: n_frames * frame_samples.  peak_normalize: scale every frame to this peak
+ * (0 = leave the modulator's output_scale 40 level; tools/test_waveform_simple.cpp:365-371 uses 0.8) */
+int ria_gpu_tx_batch(ria_gpu_handle h, const uint8_t* info_dev, int n_frames, float peak_normalize,
+                     float* samples_out_dev, void* stream);
+
+/* Builds serialized v2 data frames (makeFixedDataFrame("TEST","RX",seq,payload).serialize(),
+ * frame_v2.cpp:1890-1912, :502-554) with payload bytes drawn from a counter RNG: seq = first_seq + f. */
+int ria_gpu_make_frames(ria_gpu_handle h, uint64_t seed, int first_seq, int n_frames,
+                        uint8_t* info_out_dev, void* stream);
+
+/* ---- channel simulator (sim::WattersonChannel, src/sim/hf_channel.hpp:35-303, presets :411-488)
+ * kind: 0 awgn, 1 good, 2 moderate, 3 poor, 4 flutter.  In place on n_frames * frame_samples.
+ * Frame f uses the counter-RNG stream (seed, first_frame + f): results do not depend on how frames
+ * are split over calls or GPUs.  Statistical (not bit) parity with the reference's mt19937 stream. */
+int ria_gpu_channel_batch(ria_gpu_handle h, int kind, float snr_db, uint64_t seed, uint64_t first_frame,
+                          float* samples_dev, int n_frames, void* stream);
+
+/* ---- debug / test hooks ----------------------------------------------------------------------- */
+/* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
+ * math the kernels use on n arguments (tests compare against the host libm). */
+int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n,
+                       float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIA_GPU_H */

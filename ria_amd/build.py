@@ -1,0 +1,48 @@
+"""Build libria_gpu.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libria_gpu.so")
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _sources():
+    out = [os.path.join(HERE, "..", "include", "ria_gpu.h")]
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".hpp")):
+            out.append(os.path.join(CSRC, f))
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def build(force=False, verbose=False):
+    """Compile ria_amd/csrc/ria_gpu.hip -> ria_amd/lib/libria_gpu.so. Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(LIB):
+            return LIB  # prebuilt library shipped with the snapshot, no compiler on this box
+        raise RuntimeError("hipcc not found and no prebuilt libria_gpu.so")
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "ria_gpu.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,94 @@
+"""ctypes binding of include/ria_gpu.h.  Device memory comes from torch (plumbing only): every
+wrapper takes CUDA/HIP tensors and passes raw device pointers across the C ABI."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+RIA_OK = 0
+MOD = {"DBPSK": 0, "BPSK": 1, "DQPSK": 2, "QPSK": 3, "D8PSK": 4, "QAM16": 6, "QAM32": 7, "QAM64": 8, "QAM256": 10}
+RATE = {"R1_4": 0, "R1_3": 1, "R1_2": 2, "R2_3": 3, "R3_4": 4, "R5_6": 5}
+DECODE_PHASE0, DECODE_PERTURB, DECODE_CRC_RECOVER, DECODE_FULL = 1, 2, 4, 7
+DECODE_NO_CHANNEL_DEINTERLEAVE = 0x100
+
+# every symbol include/ria_gpu.h declares
+EXPORTS = [
+    "ria_gpu_abi_version", "ria_gpu_default_config", "ria_gpu_create", "ria_gpu_destroy", "ria_gpu_last_error",
+    "ria_gpu_get_geometry", "ria_gpu_demod_batch", "ria_gpu_decode_batch", "ria_gpu_ldpc_decode_batch",
+    "ria_gpu_rx_batch", "ria_gpu_rx_frames_host", "ria_gpu_tx_batch", "ria_gpu_make_frames",
+    "ria_gpu_channel_batch", "ria_gpu_debug_math",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "device", "modulation", "code_rate", "fft_size",
+                                          "num_carriers", "cyclic_prefix", "sample_rate", "center_freq",
+                                          "max_batch")] + [("reserved", C.c_int32 * 6)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("pilot_spacing", "n_pilots", "n_data_carriers", "bits_per_carrier",
+                                          "bits_per_symbol", "n_data_symbols", "samples_per_symbol",
+                                          "frame_samples", "llrs_per_frame", "info_bits", "bytes_per_codeword",
+                                          "info_bytes_per_frame", "ldpc_max_iterations", "ldpc_edges")] + \
+               [("reserved", C.c_int32 * 2)]
+
+
+class FrameMeta(C.Structure):
+    _fields_ = [("cfo_hz", C.c_float), ("flags", C.c_uint32), ("abs_position", C.c_uint64)]
+
+
+class FrameStatus(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("snr_db", "cfo_hz", "fading_index", "noise_variance", "lts_phase_slope",
+                                          "snr_linear", "corr_phase")] + [("n_llr", C.c_int32)]
+
+
+class DecodeStatus(C.Structure):
+    _fields_ = [("cw_ok", C.c_uint8 * 4), ("iterations", C.c_uint16 * 4), ("attempts", C.c_uint8 * 4),
+                ("frame_valid", C.c_uint8), ("needs_recovery", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_needed=True):
+    """Loads libria_gpu.so; raises (never falls back) if it cannot be built or loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build() if build_if_needed else _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError("libria_gpu.so is missing: run `python -m ria_amd.build`")
+    L = C.CDLL(path)
+    vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+    L.ria_gpu_abi_version.restype = i32
+    L.ria_gpu_default_config.argtypes = [C.POINTER(Config)]
+    L.ria_gpu_default_config.restype = None
+    L.ria_gpu_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.ria_gpu_destroy.argtypes = [vp]
+    L.ria_gpu_destroy.restype = None
+    L.ria_gpu_last_error.argtypes = [vp]
+    L.ria_gpu_last_error.restype = C.c_char_p
+    L.ria_gpu_get_geometry.argtypes = [vp, C.POINTER(Geometry)]
+    L.ria_gpu_demod_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    L.ria_gpu_decode_batch.argtypes = [vp, vp, i32, i32, u32, vp, vp, vp]
+    L.ria_gpu_ldpc_decode_batch.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp]
+    L.ria_gpu_rx_batch.argtypes = [vp, vp, vp, vp, i32, u32, vp, vp, vp, vp, vp]
+    L.ria_gpu_rx_frames_host.argtypes = [vp, vp, vp, i32, u32, vp, vp, vp, vp]
+    L.ria_gpu_tx_batch.argtypes = [vp, vp, i32, f32, vp, vp]
+    L.ria_gpu_make_frames.argtypes = [vp, u64, i32, i32, vp, vp]
+    L.ria_gpu_channel_batch.argtypes = [vp, i32, f32, u64, u64, vp, i32, vp]
+    L.ria_gpu_debug_math.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+    for name in EXPORTS:
+        if name not in ("ria_gpu_default_config", "ria_gpu_destroy", "ria_gpu_last_error"):
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+class RiaError(RuntimeError):
+    pass

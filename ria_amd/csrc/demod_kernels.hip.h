@@ -1,0 +1,742 @@
+// ria_amd/csrc/demod_kernels.hip.h — OFDM-CHIRP frame demodulator for gfx950: audio samples -> LLRs.
+//
+// Replaces OFDMChirpWaveform::process (src/waveform/ofdm_chirp_waveform.cpp:391-468) and
+// OFDMDemodulator::processPresynced (src/ofdm/demodulator.cpp:1250-1414) with everything they call:
+//   toBaseband/extractSymbol      src/ofdm/channel_equalizer.cpp:99-187   (+ NCO filters.cpp:228-238)
+//   FFT::forward (radix-2 DIT)    src/dsp/fft.cpp:96-140
+//   estimateChannelFromLTS        channel_equalizer.cpp:193-643
+//   updateChannelEstimate         channel_equalizer.cpp:645-1043
+//   equalize / hardDecision       channel_equalizer.cpp:1259-1451, :1168-1230
+//   demodulateSymbol + demappers  src/ofdm/demodulator.cpp:208-508, src/ofdm/soft_demap.hpp
+//
+// Mapping: one 256-thread workgroup per frame.
+//   phase F  the 4 wavefronts each take one OFDM symbol at a time: 1024-sample tile staged through LDS,
+//            downconverted with a host-built NCO table (the reference mixer restarts at phase 0 every
+//            frame), 1024-point FFT as three in-register radix-16/16/4 passes whose butterflies are the
+//            reference's radix-2 DIT butterflies (same twiddle table, same operand order, no FMA
+//            contraction) so every output bin is bit-identical; only the 59 used bins are kept.
+//   phase E  wavefront 0 runs the sequential estimator/equaliser/demapper with lane = logical carrier;
+//            every reduction the reference performs as a left-to-right float loop is reproduced as an
+//            ordered readlane sum, so branch scalars (residual-CFO gate, CPE gate, fade erasure, DD
+//            acceptance) see the same bits as on the CPU.
+// Transcendentals come from devmath.h (bit-identical to glibc).  Compile with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ria_gpu.h"
+#include "devmath.h"
+#include "host_tables.hpp"
+
+namespace ria {
+
+struct DemodConst {
+    int mod, coherent, n_data, n_pilot, bits_per_carrier, bits_per_symbol, n_data_symbols, n_llr;
+    unsigned long long data_mask, pilot_mask;
+    float ce_margin;
+    int bin[64];          // logical carrier -> FFT bin
+    int kk[64];           // signed bin index
+    int is_pilot[64];
+    int ord[64];          // data ordinal or pilot ordinal
+    float tx_re[64], tx_im[64];   // LTS value transmitted on this carrier
+    int lo_lane[64], hi_lane[64]; // logical index of the neighbouring pilots of a data carrier, or -1
+    float alpha[64];
+};
+
+inline float ce_margin_for(int mod) {  // soft_demap.hpp:309-332
+    switch (mod) {
+        case RIA_MOD_D8PSK: return 1.1f;
+        case RIA_MOD_QAM16: return 1.2f;
+        case RIA_MOD_QAM32: return 1.5f;
+        case RIA_MOD_QAM64: return 1.8f;
+        case RIA_MOD_QAM256: return 2.5f;
+        default: return 1.0f;
+    }
+}
+
+inline DemodConst build_demod_const(const CarrierPlan& p, int mod, const ria_gpu_geometry& g) {
+    DemodConst k{};
+    k.mod = mod;
+    k.coherent = is_coherent(mod) ? 1 : 0;
+    k.n_data = p.n_data;
+    k.n_pilot = p.n_pilot;
+    k.bits_per_carrier = g.bits_per_carrier;
+    k.bits_per_symbol = g.bits_per_symbol;
+    k.n_data_symbols = g.n_data_symbols;
+    k.n_llr = g.llrs_per_frame;
+    k.ce_margin = ce_margin_for(mod);
+    int d = 0, pi = 0;
+    for (int l = 0; l < kCarriers; ++l) {
+        k.bin[l] = p.all_bin[l];
+        k.kk[l] = (p.all_bin[l] <= kFFT / 2) ? p.all_bin[l] : p.all_bin[l] - kFFT;
+        k.is_pilot[l] = p.is_pilot[l];
+        k.lo_lane[l] = k.hi_lane[l] = -1;
+        if (p.is_pilot[l]) {
+            k.ord[l] = pi;
+            k.tx_re[l] = p.pilot_seq[pi];
+            k.tx_im[l] = 0.0f;
+            k.pilot_mask |= 1ull << l;
+            ++pi;
+        } else {
+            k.ord[l] = d;
+            k.tx_re[l] = p.sync_re[d % kCarriers];
+            k.tx_im[l] = p.sync_im[d % kCarriers];
+            k.data_mask |= 1ull << l;
+            k.lo_lane[l] = p.interp_lo[d] >= 0 ? p.pilot_logical[p.interp_lo[d]] : -1;
+            k.hi_lane[l] = p.interp_hi[d] >= 0 ? p.pilot_logical[p.interp_hi[d]] : -1;
+            k.alpha[l] = p.interp_alpha[d];
+            ++d;
+        }
+    }
+    return k;
+}
+
+struct DemodArgs {
+    const DemodConst* k;
+    const float2* twiddle;   // [512]
+    const float2* nco;       // [frame_samples] (cos, sin) of the RX mixer
+    const float* samples;
+    const uint64_t* offsets; // nullable
+    const ria_frame_meta* meta;  // nullable
+    int n_frames;
+    float* llr_out;
+    int llr_stride;
+    ria_frame_status* status;  // nullable
+};
+
+// ---------------------------------------------------------------- complex helpers (reference semantics)
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {  // naive, no FMA
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cdivc(float2 x, float2 y) {  // libgcc __divsc3: double, one rounding
+    double a = x.x, b = x.y, c = y.x, d = y.y;
+    double den = c * c + d * d;
+    return make_float2(static_cast<float>((a * c + b * d) / den), static_cast<float>((b * c - a * d) / den));
+}
+__device__ __forceinline__ float cabs_(float2 a) { return hypotf_glibc(a.x, a.y); }
+__device__ __forceinline__ float cnorm(float2 a) { return a.x * a.x + a.y * a.y; }
+__device__ __forceinline__ float carg_(float2 a) { return atan2f_glibc(a.y, a.x); }
+__device__ __forceinline__ float2 cexpj(float ph) { return make_float2(cosf_glibc(ph), sinf_glibc(ph)); }
+__device__ __forceinline__ float2 conj_(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float maxf_(float a, float b) { return (a < b) ? b : a; }  // std::max
+__device__ __forceinline__ float minf_(float a, float b) { return (b < a) ? b : a; }  // std::min
+
+// Left-to-right float sum over the lanes set in `mask` (ascending lane = the reference's loop order).
+// Lanes outside the mask must pass +0.0f (x + 0 == x bit-for-bit while the accumulator starts at +0).
+__device__ __forceinline__ float ordered_sum(float term, unsigned long long mask) {
+    float acc = 0.0f;
+    while (mask) {
+        int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), l));
+    }
+    return acc;
+}
+__device__ __forceinline__ float lane_read(float v, int l) { return __shfl(v, l); }
+
+// ---------------------------------------------------------------- 1024-point FFT by one wavefront
+constexpr int kFftBufFloats2 = 1088;  // 1024 + 64 padding slots (index i lives at i + (i >> 4))
+
+__device__ __forceinline__ void bfly(float2& a, float2& b, float2 w) {  // fft.cpp:113-117
+    float2 t = cmul(w, b);
+    b = make_float2(a.x - t.x, a.y - t.y);
+    a = make_float2(a.x + t.x, a.y + t.y);
+}
+
+// buf[0..1023] holds the time samples in natural order on entry (plain layout).  On exit the 59 used
+// bins are written to Yrow[logical carrier].
+__device__ inline void fft1024_wave(float2* buf, const float2* __restrict__ tw, float2* Yrow, int lane) {
+    float2 x[16];
+    // pass 1: bit-reversed gather, stages 1-4 on indices 16*lane + r
+    {
+        int rl = __brev(static_cast<unsigned>(lane)) >> 26;  // 6-bit reverse
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int r4 = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+            x[r] = buf[rl + 64 * r4];
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 1; s <= 4; ++s) {
+        const int half = 1 << (s - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((r & half) == 0) {
+                int k = r & (half - 1);
+                bfly(x[r], x[r + half], tw[k << (10 - s)]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[17 * lane + r] = x[r];
+    wave_sync();
+    // pass 2: stages 5-8 on indices a + 16*r2 + 256*hi
+    {
+        const int a = lane & 15, hi = lane >> 4;
+        const int base = a + 272 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = buf[base + 17 * r];
+#pragma unroll
+        for (int s = 5; s <= 8; ++s) {
+            const int hr = 1 << (s - 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((r & hr) == 0) {
+                    int k = a + 16 * (r & (hr - 1));
+                    bfly(x[r], x[r + hr], tw[k << (10 - s)]);
+                }
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[base + 17 * r] = x[r];
+    }
+    wave_sync();
+    // pass 3: stages 9-10 on indices b + 256*q; only bases that feed a used bin (b in 1..30 -> q=0
+    // output, b in 227..255 -> q=3 output) are computed.
+#pragma unroll
+    for (int t = 0; t < 4; t += 3) {
+        int b = lane + 64 * t;
+        int pa = b + (b >> 4);
+        float2 y0 = buf[pa], y1 = buf[pa + 272], y2 = buf[pa + 544], y3 = buf[pa + 816];
+        float2 w9 = tw[b << 1];
+        bfly(y0, y1, w9);
+        bfly(y2, y3, w9);
+        bfly(y0, y2, tw[b]);
+        bfly(y1, y3, tw[b + 256]);
+        if (t == 0) { if (lane >= 1 && lane <= 30) Yrow[28 + lane] = y0; }      // bins 1..30  -> logical 29..58
+        else        { if (lane >= 35) Yrow[lane - 35] = y3; }                    // bins 995..1023 -> logical 0..28
+    }
+    wave_sync();
+}
+
+// ---------------------------------------------------------------- soft demappers (soft_demap.hpp)
+__device__ __forceinline__ float clip_llr(float llr) {  // :22-29
+    float c = maxf_(-20.0f, minf_(20.0f, llr));
+    if (fabs_(c) < 0.01f) c = (c >= 0.0f) ? 0.01f : -0.01f;
+    return c;
+}
+
+__device__ inline int demap_symbol(int mod, float2 sym, float2 prev, float nv, float* o) {
+    float I = sym.x, Q = sym.y;
+    switch (mod) {
+        case RIA_MOD_BPSK: o[0] = clip_llr(fdiv(-2.0f * I, nv)); return 1;
+        case RIA_MOD_QPSK: {
+            float sc = fdiv(-2.0f * 0.7071067811865476f, nv);
+            o[0] = clip_llr(I * sc); o[1] = clip_llr(Q * sc); return 2;
+        }
+        case RIA_MOD_QAM16: {
+            float sc = fdiv(2.0f, nv);
+            const float T = 0.6324555320336759f;
+            o[0] = clip_llr(-sc * I); o[1] = clip_llr(sc * (fabs_(I) - T));
+            o[2] = clip_llr(-sc * Q); o[3] = clip_llr(sc * (fabs_(Q) - T));
+            return 4;
+        }
+        case RIA_MOD_QAM32: {
+            const float IL[4] = {-3, -1, 1, 3}, QL[8] = {-7, -5, -3, -1, 1, 3, 5, 7};
+            const int IG[4] = {0, 1, 3, 2}, QG[8] = {0, 1, 3, 2, 6, 7, 5, 4};
+            const float S = 0.1961161351381840f;
+            float sf = fdiv(2.0f, nv);
+            float m0[5], m1[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) { m0[b] = 1e10f; m1[b] = 1e10f; }
+            for (int qi = 0; qi < 8; ++qi)
+                for (int ii = 0; ii < 4; ++ii) {
+                    float dr = I - IL[ii] * S, di = Q - QL[qi] * S;
+                    float d2 = dr * dr + di * di;
+                    int bits = (QG[qi] << 2) | IG[ii];
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) {
+                        if (bits & (1 << (4 - b))) { if (d2 < m1[b]) m1[b] = d2; }
+                        else { if (d2 < m0[b]) m0[b] = d2; }
+                    }
+                }
+#pragma unroll
+            for (int b = 0; b < 5; ++b) o[b] = clip_llr(sf * (m1[b] - m0[b]));
+            return 5;
+        }
+        case RIA_MOD_QAM64: {
+            float sc = fdiv(2.0f, nv);
+            const float D2 = 0.3086067f, D4 = 0.6172134f;
+            o[0] = clip_llr(-sc * I); o[1] = clip_llr(sc * (fabs_(I) - D4)); o[2] = clip_llr(sc * (fabs_(fabs_(I) - D4) - D2));
+            o[3] = clip_llr(-sc * Q); o[4] = clip_llr(sc * (fabs_(Q) - D4)); o[5] = clip_llr(sc * (fabs_(fabs_(Q) - D4) - D2));
+            return 6;
+        }
+        case RIA_MOD_QAM256: {
+            float sc = fdiv(2.0f, nv);
+            const float D2 = 0.1290994f, D4 = 0.2581989f, D8 = 0.5163978f;
+            float v2[2] = {I, Q};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float x = v2[a];
+                o[4 * a + 0] = clip_llr(-sc * x);
+                o[4 * a + 1] = clip_llr(sc * (fabs_(x) - D8));
+                o[4 * a + 2] = clip_llr(sc * (fabs_(fabs_(x) - D8) - D4));
+                o[4 * a + 3] = clip_llr(sc * (fabs_(fabs_(fabs_(x) - D8) - D4) - D2));
+            }
+            return 8;
+        }
+        case RIA_MOD_DBPSK: {
+            float2 diff = cmul(sym, conj_(prev));
+            float pd = atan2f_glibc(diff.y, diff.x);
+            float sp = cabs_(sym) * cabs_(prev);
+            if (sp < 1e-6f) { o[0] = 0.0f; return 1; }
+            float dnv = 2.0f * nv;
+            float conf = fdiv(2.0f * sp, dnv);
+            o[0] = clip_llr(conf * cosf_glibc(pd));
+            return 1;
+        }
+        case RIA_MOD_DQPSK: {
+            float2 diff = cmul(sym, conj_(prev));
+            float dI = diff.x, dQ = diff.y, dm = cabs_(diff);
+            if (dm < 1e-6f) { o[0] = 0.0f; o[1] = 0.0f; return 2; }
+            float dnv = 2.0f * nv;
+            float sp = cabs_(sym) * cabs_(prev);
+            float snr = fdiv(sp, dnv);
+            float sc = 2.0f * fsqrt(snr);
+            const float pi_f = 3.14159265358979f;
+            float ph = atan2f_glibc(dQ, dI);
+            o[0] = clip_llr(sc * sinf_glibc(ph + fdiv(pi_f, 4.0f)));
+            o[1] = clip_llr(fdiv(sc * (fabs_(dI) - fabs_(dQ)), dm));
+            return 2;
+        }
+        default: return 0;
+    }
+}
+
+__device__ __forceinline__ float2 hard_decision(float2 s, int mod) {  // channel_equalizer.cpp:1168-1230
+    switch (mod) {
+        case RIA_MOD_BPSK: return make_float2(s.x > 0 ? 1.0f : -1.0f, 0.0f);
+        case RIA_MOD_QAM16: {
+            auto sl = [](float x) { return (x < -0.4f) ? -0.9487f : (x < 0.0f) ? -0.3162f : (x < 0.4f) ? 0.3162f : 0.9487f; };
+            return make_float2(sl(s.x), sl(s.y));
+        }
+        case RIA_MOD_QAM32: {
+            const float d = 0.1961161351381840f;
+            float x = s.x, y = s.y;
+            float I = (x < -2 * d) ? -3 * d : (x < 0) ? -d : (x < 2 * d) ? d : 3 * d;
+            float Q = (y < -6 * d) ? -7 * d : (y < -4 * d) ? -5 * d : (y < -2 * d) ? -3 * d : (y < 0) ? -d
+                    : (y < 2 * d) ? d : (y < 4 * d) ? 3 * d : (y < 6 * d) ? 5 * d : 7 * d;
+            return make_float2(I, Q);
+        }
+        case RIA_MOD_QAM64: {
+            const float d = 0.1543f;
+            auto sl = [d](float y) {
+                return (y < -6 * d) ? -7 * d : (y < -4 * d) ? -5 * d : (y < -2 * d) ? -3 * d : (y < 0) ? -d
+                     : (y < 2 * d) ? d : (y < 4 * d) ? 3 * d : (y < 6 * d) ? 5 * d : 7 * d;
+            };
+            return make_float2(sl(s.x), sl(s.y));
+        }
+        default: return make_float2(s.x > 0 ? 0.7071f : -0.7071f, s.y > 0 ? 0.7071f : -0.7071f);
+    }
+}
+
+// ---------------------------------------------------------------- the frame kernel
+constexpr int kDemodThreads = 256;
+// LDS: 4 FFT tiles + Y[16+][64]; the LLR staging area aliases FFT tiles 1..3 (idle in phase E)
+constexpr int kMaxSymbols = 40;  // 2 LTS + up to 38 data symbols (DBPSK R1/4 needs 2592/53 = 49 -> see launch check)
+
+struct DemodShared {
+    float cfo, theta0;          // current CFO and correction phase at frame start
+    int rerun;
+    float sym_theta[64];        // correction phase at the first sample of each symbol
+};
+
+__device__ inline void demod_fft_phase(const DemodArgs& A, const DemodConst& K, const float* __restrict__ x,
+                                       int n_sym, float2* tiles, float2* Y, DemodShared* sh, int lane, int wave) {
+    const float cfo = sh->cfo;
+    const bool use_cfo = fabs_(cfo) > 0.01f;
+    const float inc = static_cast<float>(-2.0f * 3.14159265358979323846 * static_cast<double>(cfo) / 48000.0);
+    if (use_cfo) {
+        // channel_equalizer.cpp:132-144: float phase recurrence over EVERY sample (CP included), wrapped
+        // with double-precision pi.  Serial by construction; one lane walks it and records the phase at
+        // each symbol start, then each wave re-walks its own symbol.
+        if (wave == 0 && lane == 0) {
+            float th = sh->theta0;
+            for (int s = 0; s < n_sym; ++s) {
+                sh->sym_theta[s] = th;
+                for (int i = 0; i < kSym; ++i) {
+                    th += inc;
+                    if (static_cast<double>(th) > 3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) - 2.0f * 3.14159265358979323846);
+                    else if (static_cast<double>(th) < -3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) + 2.0f * 3.14159265358979323846);
+                }
+            }
+            sh->sym_theta[n_sym] = th;
+        }
+        __syncthreads();
+    }
+    float2* buf = tiles + wave * kFftBufFloats2;
+    for (int s = wave; s < n_sym; s += 4) {
+        float th_reg[16];
+        if (use_cfo) {
+            // lane 0 walks this symbol's 1152 phases into the (still free) tile, all lanes pick theirs up
+            float* thb = reinterpret_cast<float*>(buf);
+            if (lane == 0) {
+                float th = sh->sym_theta[s];
+                for (int i = 0; i < kSym; ++i) {
+                    thb[i] = th;
+                    th += inc;
+                    if (static_cast<double>(th) > 3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) - 2.0f * 3.14159265358979323846);
+                    else if (static_cast<double>(th) < -3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) + 2.0f * 3.14159265358979323846);
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) th_reg[4 * c + e] = thb[kCP + 4 * lane + 256 * c + e];
+            wave_sync();
+        }
+        // stage + downconvert 1024 samples (cyclic prefix dropped): 16 B per lane per load, coalesced
+        const float* xs = x + s * kSym + kCP;
+        const float2* osc = A.nco + s * kSym + kCP;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int j = 4 * lane + 256 * c;
+            float4 v = *reinterpret_cast<const float4*>(xs + j);
+            float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float2 o = osc[j + e];
+                float2 m = make_float2(xv[e] * o.x, xv[e] * -o.y);  // samples[i] * conj(osc)
+                if (use_cfo) m = cmul(m, cexpj(th_reg[4 * c + e]));
+                buf[j + e] = m;
+            }
+        }
+        wave_sync();
+        fft1024_wave(buf, A.twiddle, Y + s * 64, lane);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DemodConst& K = *A.k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x;
+    const int n_sym = 2 + K.n_data_symbols;
+    float2* tiles = reinterpret_cast<float2*>(smem);                       // 4 * 1088 float2
+    float2* Y = tiles + 4 * kFftBufFloats2;                                // [n_sym][64]
+    DemodShared* sh = reinterpret_cast<DemodShared*>(Y + static_cast<size_t>(n_sym) * 64);
+    float* llr_lds = reinterpret_cast<float*>(tiles + kFftBufFloats2);     // aliases tiles 1..3 in phase E
+
+    const float* x = A.samples + (A.offsets ? A.offsets[frame] : static_cast<uint64_t>(frame) * n_sym * kSym);
+    if (threadIdx.x == 0) {
+        float cfo = 0.0f;
+        double init = 0.0;
+        uint32_t fl = 0;
+        if (A.meta) {
+            cfo = A.meta[frame].cfo_hz;
+            fl = A.meta[frame].flags;
+            // ofdm_chirp_waveform.cpp:402-411
+            float ip = static_cast<float>(-2.0f * 3.14159265358979323846 * static_cast<double>(cfo) *
+                                          static_cast<double>(A.meta[frame].abs_position) / 48000.0);
+            while (static_cast<double>(ip) > 3.14159265358979323846) ip = static_cast<float>(static_cast<double>(ip) - 2.0f * 3.14159265358979323846);
+            while (static_cast<double>(ip) < -3.14159265358979323846) ip = static_cast<float>(static_cast<double>(ip) + 2.0f * 3.14159265358979323846);
+            init = ip;
+        }
+        (void)fl;
+        sh->cfo = cfo;
+        sh->theta0 = static_cast<float>(init);
+        sh->rerun = 0;
+    }
+    __syncthreads();
+    const bool negate_lts0 = A.meta && (A.meta[frame].flags & 1u);
+
+    // ================= phase F: all symbols through the FFT with the CFO the host supplied
+    demod_fft_phase(A, K, x, n_sym, tiles, Y, sh, lane, wave);
+
+    // per-lane estimator state (wave 0; lane = logical carrier)
+    float2 H = make_float2(1.0f, 0.0f);
+    float noise_var = 0.1f, snr_lin = 1.0f, fading = 0.0f, slope = 0.0f;
+    int snr_count = 0;
+    const bool is_car = lane < kCarriers;
+    const bool is_pil = is_car && K.is_pilot[lane];
+    const bool is_dat = is_car && !K.is_pilot[lane];
+    const unsigned long long dmask = K.data_mask, pmask = K.pilot_mask;
+    const float2 txv = make_float2(K.tx_re[lane], K.tx_im[lane]);
+    const float lsign = negate_lts0 ? -1.0f : 1.0f;
+    float2 H0 = make_float2(0, 0), H1 = make_float2(0, 0);
+
+    // ================= LTS channel estimate (channel_equalizer.cpp:193-643), possibly twice
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wave == 0) {
+            float2 y0 = Y[0 * 64 + lane], y1 = Y[1 * 64 + lane];
+            y0 = make_float2(lsign * y0.x, lsign * y0.y);  // burst marker: first LTS was negated on air
+            if (is_car) { H0 = cdivc(y0, txv); H1 = cdivc(y1, txv); }
+            bool rerun = false;
+            if (pass == 0) {
+                bool v = is_dat && cabs_(H0) > 0.01f && cabs_(H1) > 0.01f;
+                float2 diff = cmul(H1, conj_(H0));
+                float mag = cabs_(diff);
+                v = v && mag > 1e-6f;
+                float tr = v ? fdiv(diff.x, mag) : 0.0f, ti = v ? fdiv(diff.y, mag) : 0.0f;
+                float sr = ordered_sum(tr, dmask), si = ordered_sum(ti, dmask);
+                int cnt = __popcll(__ballot(v));
+                if (cnt > 10) {
+                    float avg = atan2f_glibc(si, sr);
+                    float dur = fdiv(1152.0f, 48000.0f);
+                    float res = static_cast<float>(static_cast<double>(avg) / (2.0f * 3.14159265358979323846 * static_cast<double>(dur)));
+                    if (fabs_(res) > 0.3f && fabs_(res) < 5.0f) {
+                        rerun = true;
+                        if (lane == 0) { sh->cfo = sh->cfo + res; sh->rerun = 1; }
+                    }
+                }
+            }
+            (void)rerun;
+        }
+        __syncthreads();
+        if (pass == 0 && sh->rerun) {
+            // mixer.reset(), phase restored to its value at training start, corrected CFO: redo all symbols
+            demod_fft_phase(A, K, x, n_sym, tiles, Y, sh, lane, wave);
+        } else {
+            break;
+        }
+    }
+
+    if (wave != 0) goto write_out;
+    {
+        // H := last LTS symbol
+        H = is_car ? H1 : make_float2(1.0f, 0.0f);
+        {   // phase slope over adjacent logical carriers
+            float2 hn = make_float2(lane_read(H.x, lane + 1), lane_read(H.y, lane + 1));
+            bool v = (lane < kCarriers - 1) && cabs_(H) > 0.01f && cabs_(hn) > 0.01f;
+            float2 diff = cmul(hn, conj_(H));
+            float mag = cabs_(diff);
+            v = v && mag > 1e-6f;
+            float tr = v ? fdiv(diff.x, mag) : 0.0f, ti = v ? fdiv(diff.y, mag) : 0.0f;
+            unsigned long long m58 = (1ull << (kCarriers - 1)) - 1ull;
+            float sr = ordered_sum(tr, m58), si = ordered_sum(ti, m58);
+            int cnt = __popcll(__ballot(v));
+            if (cnt > 0) slope = atan2f_glibc(fdiv(si, static_cast<float>(cnt)), fdiv(sr, static_cast<float>(cnt)));
+        }
+        {   // noise variance + SNR from H1 - H0
+            bool v = is_dat && cabs_(H0) > 1e-6f && cabs_(H1) > 1e-6f;
+            float2 d = make_float2(H1.x - H0.x, H1.y - H0.y);
+            float tn = v ? cnorm(d) : 0.0f;
+            float ts = v ? fdiv(cnorm(H0) + cnorm(H1), 2.0f) : 0.0f;
+            float ns = ordered_sum(tn, dmask), ss = ordered_sum(ts, dmask);
+            int cnt = __popcll(__ballot(v));
+            if (cnt > 0) {
+                float nv = fdiv(ns, 4.0f * static_cast<float>(cnt));
+                float sp = fdiv(ss, static_cast<float>(cnt));
+                float snr = fdiv(sp, maxf_(nv, 1e-10f));
+                snr = maxf_(3.16f, minf_(10000.0f, snr));
+                noise_var = nv;
+                snr_lin = snr;
+            }
+        }
+        {   // fading index of |H| over data carriers
+            float a = is_dat ? cabs_(H) : 0.0f;
+            float mean = fdiv(ordered_sum(a, dmask), static_cast<float>(K.n_data));
+            float dd_ = a - mean;
+            float var = fdiv(ordered_sum(is_dat ? dd_ * dd_ : 0.0f, dmask), static_cast<float>(K.n_data));
+            fading = (mean > 0.01f) ? fdiv(fsqrt(var), mean) : 0.0f;
+        }
+        snr_count = 2;
+
+        // ================= data symbols
+        float2 prev_pilot = make_float2(0, 0);
+        bool have_prev = false, have_dd = false, have_ema = false, have_dprev = false, cp_init = false;
+        float dd = 0.0f, ema = 0.0f, var = 0.0f, cnv = 0.0f;
+        float2 cp_corr = make_float2(1.0f, 0.0f), dprev = make_float2(1.0f, 0.0f);
+        const int mod = K.mod;
+        const bool coh = K.coherent != 0;
+        const int kk = K.kk[lane];
+        const int lo = K.lo_lane[lane], hi = K.hi_lane[lane];
+        const float ia = K.alpha[lane];
+        const float npf = static_cast<float>(K.n_pilot), ndf = static_cast<float>(K.n_data);
+
+        for (int ds = 0; ds < K.n_data_symbols; ++ds) {
+            float2 y = Y[(2 + ds) * 64 + lane];
+            const bool first = (ds == 0);
+            // ---------- updateChannelEstimate (channel_equalizer.cpp:645-1043)
+            if (K.n_pilot > 0) {
+                float alpha = first ? 1.0f : (coh ? 0.9f : 0.5f);
+                float2 hls = is_pil ? cdivc(y, txv) : make_float2(0, 0);
+                if (coh) {
+                    cp_init = true;
+                } else if (!cp_init) {
+                    float2 hsum = make_float2(ordered_sum(hls.x, pmask), ordered_sum(hls.y, pmask));
+                    float2 havg = make_float2(fdiv(hsum.x, npf), fdiv(hsum.y, npf));
+                    float am = cabs_(havg);
+                    if (am > 0.01f) { cp_corr = make_float2(fdiv(havg.x, am), fdiv(-havg.y, am)); cp_init = true; }
+                }
+                hls = cmul(hls, cp_corr);
+                if (coh) {  // common phase error
+                    float hm = cabs_(H);
+                    float2 ratio = cmul(hls, conj_(H));
+                    float mag = cabs_(ratio);
+                    bool v = is_pil && hm > 0.01f && mag > 1e-6f;
+                    float tr = v ? fdiv(ratio.x, mag) * hm : 0.0f, ti = v ? fdiv(ratio.y, mag) * hm : 0.0f;
+                    float tw_ = v ? hm : 0.0f;
+                    float cr = ordered_sum(tr, pmask), ci = ordered_sum(ti, pmask), ws = ordered_sum(tw_, pmask);
+                    if (ws > 0.01f) {
+                        float ph = atan2f_glibc(ci, cr);
+                        if (fabs_(ph) > 0.001f) H = cmul(H, cexpj(ph));
+                    }
+                }
+                float signal_power = fdiv(ordered_sum(is_pil ? cnorm(hls) : 0.0f, pmask), npf);
+                bool nvv = is_pil && have_prev && cnorm(prev_pilot) > 1e-6f && cnorm(hls) > 1e-6f;
+                float2 dp = make_float2(hls.x - prev_pilot.x, hls.y - prev_pilot.y);
+                float noise_power_sum = ordered_sum(nvv ? cnorm(dp) : 0.0f, pmask);
+                int noise_count = __popcll(__ballot(nvv));
+                if (is_pil) {
+                    if (coh) {
+                        H = make_float2(alpha * hls.x + (1.0f - alpha) * H.x, alpha * hls.y + (1.0f - alpha) * H.y);
+                    } else {
+                        float nm = alpha * cabs_(hls) + (1.0f - alpha) * cabs_(H);
+                        float ph = carg_(H);
+                        H = make_float2(nm * cosf_glibc(ph), nm * sinf_glibc(ph));
+                    }
+                }
+                if (noise_count == 0) { noise_power_sum = fdiv(signal_power, 31.6f); noise_count = 1; }
+                prev_pilot = hls;
+                have_prev = true;
+                // interpolation between pilots
+                if (coh) {
+                    float ph = -slope * static_cast<float>(kk);
+                    float2 des = cmul(H, make_float2(cosf_glibc(ph), sinf_glibc(ph)));
+                    float2 hl = make_float2(lane_read(des.x, lo < 0 ? 0 : lo), lane_read(des.y, lo < 0 ? 0 : lo));
+                    float2 hu = make_float2(lane_read(des.x, hi < 0 ? 0 : hi), lane_read(des.y, hi < 0 ? 0 : hi));
+                    if (is_dat) {
+                        float2 ih;
+                        if (lo >= 0 && hi >= 0)
+                            ih = make_float2((1.0f - ia) * hl.x + ia * hu.x, (1.0f - ia) * hl.y + ia * hu.y);
+                        else if (lo >= 0) ih = hl;
+                        else ih = hu;
+                        float p2 = slope * static_cast<float>(kk);
+                        H = cmul(ih, make_float2(cosf_glibc(p2), sinf_glibc(p2)));
+                    }
+                } else {
+                    float am = cabs_(H);
+                    float m1 = lane_read(am, lo < 0 ? 0 : lo), m2 = lane_read(am, hi < 0 ? 0 : hi);
+                    if (is_dat) {
+                        float im = 0.0f;
+                        if (lo >= 0 && hi >= 0) im = (1.0f - ia) * m1 + ia * m2;
+                        else if (lo >= 0) im = m1;
+                        else if (hi >= 0) im = m2;
+                        float ph = carg_(H);
+                        H = make_float2(im * cosf_glibc(ph), im * sinf_glibc(ph));
+                    }
+                }
+                if (coh && have_dd && snr_count >= 3 && is_dat) {
+                    if (fabs_(dd) > 0.001f) H = cmul(H, cexpj(dd * 0.3f));
+                }
+                {   // fading index from pilot magnitudes
+                    float a = is_pil ? cabs_(hls) : 0.0f;
+                    float mean = fdiv(ordered_sum(a, pmask), npf);
+                    float df = a - mean;
+                    float vv = fdiv(ordered_sum(is_pil ? df * df : 0.0f, pmask), npf);
+                    fading = (mean > 0.01f) ? fdiv(fsqrt(vv), mean) : 0.0f;
+                }
+                if (noise_count > 0 && noise_power_sum > 0.0f && coh && noise_count > 1) {
+                    float inst = fdiv(signal_power, maxf_(noise_var, 1e-6f));
+                    inst = maxf_(0.1f, minf_(10000.0f, inst));
+                    snr_lin = 0.3f * inst + (1.0f - 0.3f) * snr_lin;
+                }
+                snr_count++;
+            }
+            // ---------- equalize (channel_equalizer.cpp:1259-1451)
+            float2 eq = make_float2(0, 0);
+            {
+                float hp = cnorm(H);
+                float avg = fdiv(ordered_sum(is_dat ? hp : 0.0f, dmask), ndf);
+                float thr = 0.25f * avg;
+                if (!coh) {
+                    float snv = noise_var;
+                    if (snv < 1e-6f) snv = fdiv(avg, 31.6f);
+                    float den = hp + snv;
+                    if (den < 1e-10f) { eq = make_float2(0, 0); cnv = 100.0f; }
+                    else {
+                        float2 pr = cmul(y, conj_(H));
+                        eq = make_float2(fdiv(pr.x, den), fdiv(pr.y, den));
+                        cnv = fdiv(snv, hp + snv);
+                    }
+                    if (hp < thr) cnv = 100.0f;
+                    cnv = maxf_(1e-6f, minf_(100.0f, cnv));
+                } else {
+                    float den = hp + noise_var;
+                    if (den < 1e-10f) { eq = make_float2(0, 0); cnv = 100.0f; }
+                    else {
+                        float2 pr = cmul(conj_(H), y);
+                        eq = make_float2(fdiv(pr.x, den), fdiv(pr.y, den));
+                        cnv = maxf_(1e-6f, minf_(100.0f, fdiv(noise_var, den)));
+                    }
+                    if (hp < thr) cnv = 100.0f;
+                    bool dd_ok = (mod == RIA_MOD_QPSK || mod == RIA_MOD_BPSK || mod == RIA_MOD_QAM16 ||
+                                  mod == RIA_MOD_QAM32 || mod == RIA_MOD_QAM64);
+                    if (dd_ok && snr_count >= 2) {
+                        have_dd = true;
+                        float mt = 0.3f, pt = 0.61f;
+                        if (mod == RIA_MOD_QAM16) { mt = 0.25f; pt = 0.44f; }
+                        else if (mod == RIA_MOD_QAM32 || mod == RIA_MOD_QAM64) { mt = 0.20f; pt = 0.35f; }
+                        if (cabs_(eq) < mt) dd = 0.0f;
+                        else {
+                            float2 dec = hard_decision(eq, mod);
+                            float pe = carg_(cmul(eq, conj_(dec)));
+                            dd = (fabs_(pe) < pt) ? -pe : 0.0f;
+                        }
+                    }
+                }
+            }
+            // ---------- demodulateSymbol (demodulator.cpp:208-508)
+            {
+                float mag = cabs_(eq);
+                if (!have_ema) { ema = mag; var = 0.0f; have_ema = true; }
+                else {
+                    float delta = mag - ema;
+                    ema += 0.3f * delta;
+                    var += 0.3f * (delta * delta - var);
+                }
+                if (!coh && !have_dprev) { dprev = make_float2(1.0f, 0.0f); have_dprev = true; }
+                float nv = cnv * K.ce_margin;
+                float msq = ema * ema + 1e-6f;
+                float nvar = fdiv(var, msq);
+                nv *= (1.0f + 10.0f * nvar);
+                float o[8];
+                int nb = demap_symbol(mod, eq, dprev, nv, o);
+                if (!coh) dprev = eq;
+                if (is_dat) {
+                    float* dst = llr_lds + ds * K.bits_per_symbol + K.ord[lane] * K.bits_per_carrier;
+                    for (int b = 0; b < nb; ++b) dst[b] = o[b];
+                }
+            }
+        }
+        if (A.status && lane == 0) {
+            ria_frame_status st;
+            // 10*log10f(x): the only transcendental on the status path that is not bit-pinned; it is
+            // a display value (OFDMDemodulator::getEstimatedSNR) and is checked to 1e-5 relative.
+            st.snr_db = 10.0f * (logf_glibc(snr_lin) * 0.43429448190325176f);
+            st.cfo_hz = sh->cfo;
+            st.fading_index = fading;
+            st.noise_variance = noise_var;
+            st.lts_phase_slope = slope;
+            st.snr_linear = snr_lin;
+            st.corr_phase = (fabs_(sh->cfo) > 0.01f) ? sh->sym_theta[n_sym] : sh->theta0;
+            st.n_llr = K.n_llr;
+            A.status[frame] = st;
+        }
+    }
+write_out:
+    __syncthreads();
+    {
+        float* dst = A.llr_out + static_cast<size_t>(frame) * A.llr_stride;
+        for (int i = threadIdx.x; i < K.n_llr; i += kDemodThreads) dst[i] = llr_lds[i];
+    }
+}
+
+inline int demod_lds_bytes(int n_sym) {
+    return 4 * kFftBufFloats2 * 8 + n_sym * 64 * 8 + static_cast<int>(sizeof(DemodShared)) + 16;
+}
+inline hipError_t demod_set_attributes() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(demod_frames_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, demod_lds_bytes(64));
+}
+inline void launch_demod(const DemodArgs& A, const ria_gpu_geometry& g, hipStream_t s) {
+    int n_sym = 2 + g.n_data_symbols;
+    hipLaunchKernelGGL(demod_frames_kernel, dim3(A.n_frames), dim3(kDemodThreads), demod_lds_bytes(n_sym), s, A);
+}
+
+}  // namespace ria

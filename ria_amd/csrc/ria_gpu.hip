@@ -1,0 +1,403 @@
+// ria_amd/csrc/ria_gpu.hip — C-ABI implementation of libria_gpu.so (include/ria_gpu.h).
+// Host-side orchestration only: table upload, workspace, kernel launches.  No torch types, no CPU
+// fallback: every entry point fails loudly if the HIP device or a launch is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ria_gpu.h"
+#include "host_tables.hpp"
+#include "ldpc_kernels.hip.h"
+#include "demod_kernels.hip.h"
+#include "tx_kernels.hip.h"
+
+using namespace ria;
+
+struct ria_gpu {
+    ria_gpu_config cfg{};
+    ria_gpu_geometry geo{};
+    CarrierPlan plan{};
+    LdpcCode code;
+    std::string err;
+    int device = 0;
+    // device tables
+    void* d_row_deg = nullptr; void* d_row_var = nullptr; void* d_col_deg = nullptr; void* d_col_slot = nullptr;
+    void* d_gather = nullptr; void* d_gather_nochan = nullptr;
+    void* d_crc_bit = nullptr; void* d_crc_init = nullptr;
+    void* d_twiddle = nullptr; void* d_nco = nullptr;
+    void* d_demod_const = nullptr;
+    void* d_tx_const = nullptr;
+    // workspace
+    float* d_llr_ws = nullptr;            // max_batch * llrs_per_frame (fused path)
+    LdpcDev ldpc_dev{};
+};
+
+namespace {
+
+int fail(ria_gpu_handle h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(h, RIA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+hipError_t upload(void** dst, const std::vector<T>& v) {
+    hipError_t e = hipMalloc(dst, v.size() * sizeof(T) + 16);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+uint16_t crc16_host(const uint8_t* d, int n, uint16_t init) {  // frame_v2.cpp:115-128
+    uint16_t crc = init;
+    for (int i = 0; i < n; ++i) {
+        crc ^= static_cast<uint16_t>(d[i]) << 8;
+        for (int j = 0; j < 8; ++j) crc = (crc & 0x8000) ? static_cast<uint16_t>((crc << 1) ^ 0x1021) : static_cast<uint16_t>(crc << 1);
+    }
+    return crc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ria_gpu_abi_version(void) { return RIA_GPU_ABI_VERSION; }
+
+void ria_gpu_default_config(ria_gpu_config* cfg) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = RIA_GPU_ABI_VERSION;
+    cfg->device = 0;
+    cfg->modulation = RIA_MOD_QAM16;
+    cfg->code_rate = RIA_RATE_1_2;
+    cfg->fft_size = 1024;
+    cfg->num_carriers = 59;
+    cfg->cyclic_prefix = 128;
+    cfg->sample_rate = 48000;
+    cfg->center_freq = 1500;
+    cfg->max_batch = 4096;
+}
+
+const char* ria_gpu_last_error(ria_gpu_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+void ria_gpu_destroy(ria_gpu_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
+                    h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+}
+
+int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
+    if (!cfg || !out) return RIA_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->abi_version != RIA_GPU_ABI_VERSION) return RIA_ERR_INVALID;
+    if (cfg->fft_size != 1024 || cfg->num_carriers != 59 || cfg->cyclic_prefix != 128 ||
+        cfg->sample_rate != 48000 || cfg->center_freq != 1500)
+        return RIA_ERR_UNSUPPORTED;  // the production OFDM-CHIRP shape (types.hpp:252-268)
+    if (bits_per_carrier(cfg->modulation) == 0 || cfg->modulation == RIA_MOD_D8PSK) return RIA_ERR_UNSUPPORTED;
+    if (cfg->code_rate < RIA_RATE_1_4 || cfg->code_rate > RIA_RATE_5_6) return RIA_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) return RIA_ERR_NO_DEVICE;
+    ria_gpu_handle h = new ria_gpu();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    if (h->cfg.max_batch <= 0) h->cfg.max_batch = 4096;
+    if (hipSetDevice(h->device) != hipSuccess) { delete h; return RIA_ERR_NO_DEVICE; }
+
+    h->plan = build_carrier_plan(cfg->modulation, cfg->code_rate);
+    h->code = build_ldpc(cfg->code_rate);
+    ria_gpu_geometry& g = h->geo;
+    g.pilot_spacing = h->plan.spacing;
+    g.n_pilots = h->plan.n_pilot;
+    g.n_data_carriers = h->plan.n_data;
+    g.bits_per_carrier = bits_per_carrier(cfg->modulation);
+    g.bits_per_symbol = g.n_data_carriers * g.bits_per_carrier;
+    g.n_data_symbols = (kFrameBits + g.bits_per_symbol - 1) / g.bits_per_symbol;
+    g.samples_per_symbol = kSym;
+    g.frame_samples = (2 + g.n_data_symbols) * kSym;
+    g.llrs_per_frame = g.n_data_symbols * g.bits_per_symbol;
+    g.info_bits = info_bits_for(cfg->code_rate);
+    g.bytes_per_codeword = g.info_bits / 8;
+    g.info_bytes_per_frame = 4 * g.bytes_per_codeword;
+    g.ldpc_max_iterations = recommended_iterations(cfg->code_rate);
+    g.ldpc_edges = h->code.n_edges;
+
+#define CREATE_TRY(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "ria_gpu_create: %s failed: %s\n", #expr, hipGetErrorString(e_));        \
+            ria_gpu_destroy(h);                                                                       \
+            return RIA_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+
+    CREATE_TRY(upload(&h->d_row_deg, h->code.row_deg));
+    CREATE_TRY(upload(&h->d_row_var, h->code.row_var));
+    CREATE_TRY(upload(&h->d_col_deg, h->code.col_deg));
+    CREATE_TRY(upload(&h->d_col_slot, h->code.col_slot));
+    CREATE_TRY(upload(&h->d_gather, build_rx_gather(g.bits_per_symbol, true)));
+    CREATE_TRY(upload(&h->d_gather_nochan, build_rx_gather(g.bits_per_symbol, false)));
+    {
+        // CRC-16 linear decomposition: crc(M) = crc_init[L] ^ XOR_{set bits} crc_bit[distance from end]
+        std::vector<uint16_t> bit(4 * 68 * 8 + 16), init(4 * 68 + 2);
+        std::vector<uint8_t> z(4 * 68 + 2, 0);
+        for (size_t q = 0; q < bit.size(); ++q) {
+            std::vector<uint8_t> msg(q / 8 + 1, 0);
+            msg[0] = static_cast<uint8_t>(1u << (q % 8));
+            bit[q] = crc16_host(msg.data(), static_cast<int>(msg.size()), 0);
+        }
+        for (size_t L = 0; L < init.size(); ++L) init[L] = crc16_host(z.data(), static_cast<int>(L), 0xFFFF);
+        CREATE_TRY(upload(&h->d_crc_bit, bit));
+        CREATE_TRY(upload(&h->d_crc_init, init));
+    }
+    CREATE_TRY(upload(&h->d_twiddle, build_twiddles()));
+    CREATE_TRY(upload(&h->d_nco, build_nco_table(g.frame_samples)));
+    {
+        DemodConst dc = build_demod_const(h->plan, cfg->modulation, g);
+        std::vector<DemodConst> v(1, dc);
+        CREATE_TRY(upload(&h->d_demod_const, v));
+        TxConst tc = build_tx_const(h->plan, h->code, cfg->modulation, g);
+        std::vector<TxConst> tv(1, tc);
+        CREATE_TRY(upload(&h->d_tx_const, tv));
+    }
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_llr_ws),
+                         static_cast<size_t>(h->cfg.max_batch) * g.llrs_per_frame * sizeof(float)));
+
+    LdpcDev& L = h->ldpc_dev;
+    L.k = h->code.k; L.m = h->code.m; L.n = h->code.n; L.max_col_deg = h->code.max_col_deg;
+    L.max_iter = g.ldpc_max_iterations; L.bytes_per_cw = g.bytes_per_codeword;
+    L.row_deg = static_cast<const uint8_t*>(h->d_row_deg);
+    L.row_var = static_cast<const uint16_t*>(h->d_row_var);
+    L.col_deg = static_cast<const uint8_t*>(h->d_col_deg);
+    L.col_slot = static_cast<const uint16_t*>(h->d_col_slot);
+
+    // dynamic LDS above 64 KiB must be opted into per kernel
+    int frame_lds = 4 * ldpc_wave_lds_bytes(L.m) + kFrameSharedBytes;
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_frames_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, frame_lds));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_decode_rows_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ldpc_wave_lds_bytes(L.m)));
+    CREATE_TRY(demod_set_attributes());
+#undef CREATE_TRY
+    *out = h;
+    return RIA_OK;
+}
+
+int ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out) {
+    if (!h || !out) return RIA_ERR_INVALID;
+    *out = h->geo;
+    return RIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, int max_iterations,
+                              float min_sum_factor, uint8_t* out_dev, uint8_t* ok_dev, uint16_t* iters_dev,
+                              void* stream) {
+    if (!h || !llr_dev || !out_dev || !ok_dev || !iters_dev || n_cw < 0 || max_iterations < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_ldpc_decode_batch: bad argument");
+    if (n_cw == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int lds = 4 * ldpc_wave_lds_bytes(h->ldpc_dev.m);
+    hipLaunchKernelGGL(ldpc_decode_rows_kernel, dim3((n_cw + 3) / 4), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       h->ldpc_dev, llr_dev, n_cw, max_iterations, min_sum_factor, out_dev, ok_dev, iters_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
+                         uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s) {
+    FrameDecodeArgs A;
+    A.c = h->ldpc_dev;
+    A.gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
+    A.llr = llr_dev;
+    A.llr_stride = llr_stride;
+    A.n_frames = n_frames;
+    A.flags = flags;
+    A.info_out = info_out_dev;
+    A.status = status_dev;
+    A.crc_bit = static_cast<const uint16_t*>(h->d_crc_bit);
+    A.crc_init = static_cast<const uint16_t*>(h->d_crc_init);
+    int lds = 4 * ldpc_wave_lds_bytes(h->ldpc_dev.m) + kFrameSharedBytes;
+    hipLaunchKernelGGL(decode_frames_kernel, dim3(n_frames), dim3(256), lds, s, A);
+    return RIA_OK;
+}
+
+int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
+                         uint8_t* info_out_dev, ria_decode_status* status_dev, void* stream) {
+    if (!h || !llr_dev || !info_out_dev || !status_dev || n_frames < 0 || llr_stride < kFrameBits)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_decode_batch: bad argument (llr_stride must be >= 2592)");
+    if (n_frames == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_decode(h, llr_dev, llr_stride, n_frames, flags, info_out_dev, status_dev, static_cast<hipStream_t>(stream));
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ demod
+int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
+                        const ria_frame_meta* meta_dev, int n_frames, float* llr_out_dev,
+                        ria_frame_status* status_dev, void* stream) {
+    if (!h || !samples_dev || !llr_out_dev || n_frames < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_demod_batch: bad argument");
+    if (n_frames == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DemodArgs A;
+    A.k = static_cast<const DemodConst*>(h->d_demod_const);
+    A.twiddle = static_cast<const float2*>(h->d_twiddle);
+    A.nco = static_cast<const float2*>(h->d_nco);
+    A.samples = samples_dev;
+    A.offsets = frame_offsets_dev;
+    A.meta = meta_dev;
+    A.n_frames = n_frames;
+    A.llr_out = llr_out_dev;
+    A.llr_stride = h->geo.llrs_per_frame;
+    A.status = status_dev;
+    launch_demod(A, h->geo, static_cast<hipStream_t>(stream));
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
+                     const ria_frame_meta* meta_dev, int n_frames, uint32_t flags, uint8_t* info_out_dev,
+                     ria_decode_status* decode_status_dev, float* llr_out_dev, ria_frame_status* demod_status_dev,
+                     void* stream) {
+    if (!h || !samples_dev || !info_out_dev || !decode_status_dev || n_frames < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_rx_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // Two launches on one stream: demodulate (LLRs stay in the HBM workspace / L2), then decode.
+    for (int done = 0; done < n_frames;) {
+        int nb = n_frames - done;
+        if (!llr_out_dev && nb > h->cfg.max_batch) nb = h->cfg.max_batch;
+        float* llr = llr_out_dev ? llr_out_dev + static_cast<size_t>(done) * h->geo.llrs_per_frame : h->d_llr_ws;
+        const uint64_t* offs = frame_offsets_dev ? frame_offsets_dev + done : nullptr;
+        const float* smp = frame_offsets_dev ? samples_dev : samples_dev + static_cast<size_t>(done) * h->geo.frame_samples;
+        int rc = ria_gpu_demod_batch(h, smp, offs, meta_dev ? meta_dev + done : nullptr, nb, llr,
+                                     demod_status_dev ? demod_status_dev + done : nullptr, stream);
+        if (rc != RIA_OK) return rc;
+        launch_decode(h, llr, h->geo.llrs_per_frame, nb, flags,
+                      info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame, decode_status_dev + done, s);
+        HIP_TRY(h, hipGetLastError());
+        done += nb;
+    }
+    return RIA_OK;
+}
+
+int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ria_frame_meta* meta_host, int n_frames,
+                           uint32_t flags, uint8_t* info_out_host, ria_decode_status* decode_status_host,
+                           float* llr_out_host, ria_frame_status* demod_status_host) {
+    if (!h || !samples_host || !info_out_host || !decode_status_host || n_frames <= 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_rx_frames_host: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const ria_gpu_geometry& g = h->geo;
+    float* d_s = nullptr; float* d_llr = nullptr; uint8_t* d_info = nullptr;
+    ria_decode_status* d_ds = nullptr; ria_frame_status* d_fs = nullptr; ria_frame_meta* d_m = nullptr;
+    size_t ns = static_cast<size_t>(n_frames) * g.frame_samples, nl = static_cast<size_t>(n_frames) * g.llrs_per_frame;
+    int rc = RIA_OK;
+    auto cleanup = [&]() { for (void* p_ : {(void*)d_s, (void*)d_llr, (void*)d_info, (void*)d_ds, (void*)d_fs, (void*)d_m}) (void)hipFree(p_); };
+#define H_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_s), ns * sizeof(float)));
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_llr), nl * sizeof(float)));
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_info), static_cast<size_t>(n_frames) * g.info_bytes_per_frame));
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_ds), n_frames * sizeof(ria_decode_status)));
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_fs), n_frames * sizeof(ria_frame_status)));
+    H_TRY(hipMemcpy(d_s, samples_host, ns * sizeof(float), hipMemcpyHostToDevice));
+    if (meta_host) {
+        H_TRY(hipMalloc(reinterpret_cast<void**>(&d_m), n_frames * sizeof(ria_frame_meta)));
+        H_TRY(hipMemcpy(d_m, meta_host, n_frames * sizeof(ria_frame_meta), hipMemcpyHostToDevice));
+    }
+    rc = ria_gpu_rx_batch(h, d_s, nullptr, d_m, n_frames, flags, d_info, d_ds, d_llr, d_fs, nullptr);
+    if (rc == RIA_OK) {
+        H_TRY(hipDeviceSynchronize());
+        H_TRY(hipMemcpy(info_out_host, d_info, static_cast<size_t>(n_frames) * g.info_bytes_per_frame, hipMemcpyDeviceToHost));
+        H_TRY(hipMemcpy(decode_status_host, d_ds, n_frames * sizeof(ria_decode_status), hipMemcpyDeviceToHost));
+        if (llr_out_host) H_TRY(hipMemcpy(llr_out_host, d_llr, nl * sizeof(float), hipMemcpyDeviceToHost));
+        if (demod_status_host) H_TRY(hipMemcpy(demod_status_host, d_fs, n_frames * sizeof(ria_frame_status), hipMemcpyDeviceToHost));
+    }
+#undef H_TRY
+    cleanup();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ TX / channel
+int ria_gpu_make_frames(ria_gpu_handle h, uint64_t seed, int first_seq, int n_frames, uint8_t* info_out_dev,
+                        void* stream) {
+    if (!h || !info_out_dev || n_frames < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_make_frames: bad argument");
+    if (n_frames == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_make_frames(static_cast<const TxConst*>(h->d_tx_const), static_cast<const uint16_t*>(h->d_crc_bit),
+                       static_cast<const uint16_t*>(h->d_crc_init), seed, first_seq, n_frames, h->geo, info_out_dev,
+                       static_cast<hipStream_t>(stream));
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_tx_batch(ria_gpu_handle h, const uint8_t* info_dev, int n_frames, float peak_normalize,
+                     float* samples_out_dev, void* stream) {
+    if (!h || !info_dev || !samples_out_dev || n_frames < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_tx_batch: bad argument");
+    if (n_frames == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_tx(static_cast<const TxConst*>(h->d_tx_const), static_cast<const float2*>(h->d_twiddle),
+              static_cast<const float2*>(h->d_nco), info_dev, n_frames, peak_normalize, h->geo, samples_out_dev,
+              static_cast<hipStream_t>(stream));
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_channel_batch(ria_gpu_handle h, int kind, float snr_db, uint64_t seed, uint64_t first_frame,
+                          float* samples_dev, int n_frames, void* stream) {
+    if (!h || !samples_dev || n_frames < 0 || kind < 0 || kind > 4)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_batch: bad argument");
+    if (n_frames == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_channel(kind, snr_db, seed, first_frame, samples_dev, n_frames, h->geo.frame_samples,
+                   static_cast<hipStream_t>(stream));
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ debug
+__global__ void debug_math_kernel(int op, const float* a, const float* b, int n, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r;
+    switch (op) {
+        case 0: r = sinf_glibc(x); break;
+        case 1: r = cosf_glibc(x); break;
+        case 2: r = logf_glibc(x); break;
+        case 3: r = atan2f_glibc(x, y); break;
+        case 4: r = hypotf_glibc(x, y); break;
+        case 5: r = fdiv(x, y); break;
+        default: r = fsqrt(x); break;
+    }
+    out[i] = r;
+}
+
+int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n, float* out_dev,
+                       void* stream) {
+    if (!h || !a_dev || !out_dev || n < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_debug_math: bad argument");
+    if (n == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), op,
+                       a_dev, b_dev, n, out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+"""Batched MI355X RX engine: thin Python over the C ABI (include/ria_gpu.h).
+
+`RxEngine` owns one ria_gpu handle (one modulation/code-rate pair, like one configured IWaveform).
+All heavy lifting happens in libria_gpu.so; torch only provides device buffers and streams.
+There is no CPU fallback: constructing an engine without a HIP device raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class RxEngine:
+    def __init__(self, modulation="QAM16", code_rate="R1_2", device=0, max_batch=4096):
+        if not torch.cuda.is_available():
+            raise capi.RiaError("ria_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.lib = capi.load()
+        self.modulation = capi.MOD[modulation] if isinstance(modulation, str) else int(modulation)
+        self.code_rate = capi.RATE[code_rate] if isinstance(code_rate, str) else int(code_rate)
+        cfg = capi.Config()
+        self.lib.ria_gpu_default_config(C.byref(cfg))
+        cfg.device = device
+        cfg.modulation = self.modulation
+        cfg.code_rate = self.code_rate
+        cfg.max_batch = max_batch
+        h = C.c_void_p()
+        rc = self.lib.ria_gpu_create(C.byref(cfg), C.byref(h))
+        if rc != capi.RIA_OK:
+            raise capi.RiaError(f"ria_gpu_create failed with status {rc}")
+        self.h = h
+        self.device = torch.device("cuda", device)
+        self.geo = capi.Geometry()
+        self._check(self.lib.ria_gpu_get_geometry(self.h, C.byref(self.geo)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ria_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != capi.RIA_OK:
+            raise capi.RiaError(f"libria_gpu status {rc}: {self.lib.ria_gpu_last_error(self.h).decode()}")
+
+    # ---- helpers
+    def _meta(self, n, cfo_hz, abs_pos, flags):
+        if cfo_hz is None and abs_pos is None and flags is None:
+            return None
+        m = np.zeros(n, dtype=np.dtype([("cfo_hz", "<f4"), ("flags", "<u4"), ("abs_position", "<u8")]))
+        if cfo_hz is not None:
+            m["cfo_hz"] = cfo_hz
+        if abs_pos is not None:
+            m["abs_position"] = abs_pos
+        if flags is not None:
+            m["flags"] = flags
+        return torch.from_numpy(m.view(np.uint8).reshape(n, 16)).to(self.device)
+
+    @staticmethod
+    def _status_array(t, dtype):
+        return t.cpu().numpy().view(dtype).reshape(-1)
+
+    FRAME_STATUS = np.dtype([("snr_db", "<f4"), ("cfo_hz", "<f4"), ("fading_index", "<f4"),
+                             ("noise_variance", "<f4"), ("lts_phase_slope", "<f4"), ("snr_linear", "<f4"),
+                             ("corr_phase", "<f4"), ("n_llr", "<i4")])
+    DECODE_STATUS = np.dtype([("cw_ok", "u1", 4), ("iterations", "<u2", 4), ("attempts", "u1", 4),
+                              ("frame_valid", "u1"), ("needs_recovery", "u1"), ("reserved", "u1", 2)])
+
+    # ---- batched calls (device tensors in, device tensors out)
+    def demod(self, samples, cfo_hz=None, abs_pos=None, flags=None, want_status=True):
+        """samples: float32 [n_frames, frame_samples] on the GPU -> (llr [n, llrs_per_frame], status)"""
+        n = samples.shape[0]
+        assert samples.dtype == torch.float32 and samples.is_contiguous() and samples.shape[1] == self.geo.frame_samples
+        llr = torch.empty((n, self.geo.llrs_per_frame), dtype=torch.float32, device=self.device)
+        st = torch.zeros((n, 32), dtype=torch.uint8, device=self.device) if want_status else None
+        meta = self._meta(n, cfo_hz, abs_pos, flags)
+        self._check(self.lib.ria_gpu_demod_batch(self.h, _ptr(samples), None, _ptr(meta), n, _ptr(llr), _ptr(st),
+                                                 _stream_ptr()))
+        return llr, st
+
+    def decode(self, llr, flags=capi.DECODE_FULL):
+        """llr: float32 [n_frames, >=2592] -> (info bytes [n, info_bytes_per_frame], status)"""
+        n = llr.shape[0]
+        assert llr.dtype == torch.float32 and llr.is_contiguous() and llr.shape[1] >= 2592
+        info = torch.empty((n, self.geo.info_bytes_per_frame), dtype=torch.uint8, device=self.device)
+        st = torch.zeros((n, 20), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_decode_batch(self.h, _ptr(llr), llr.shape[1], n, flags, _ptr(info), _ptr(st),
+                                                  _stream_ptr()))
+        return info, st
+
+    def rx(self, samples, flags=capi.DECODE_FULL, cfo_hz=None, abs_pos=None, meta_flags=None, want_llr=False,
+           out=None):
+        """Fused samples -> payload bytes. Returns (info, decode_status[, llr, frame_status])."""
+        n = samples.shape[0]
+        assert samples.dtype == torch.float32 and samples.is_contiguous() and samples.shape[1] == self.geo.frame_samples
+        if out is None:
+            info = torch.empty((n, self.geo.info_bytes_per_frame), dtype=torch.uint8, device=self.device)
+            st = torch.zeros((n, 20), dtype=torch.uint8, device=self.device)
+        else:
+            info, st = out
+        llr = fst = None
+        if want_llr:
+            llr = torch.empty((n, self.geo.llrs_per_frame), dtype=torch.float32, device=self.device)
+            fst = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        meta = self._meta(n, cfo_hz, abs_pos, meta_flags)
+        self._check(self.lib.ria_gpu_rx_batch(self.h, _ptr(samples), None, _ptr(meta), n, flags, _ptr(info), _ptr(st),
+                                              _ptr(llr), _ptr(fst), _stream_ptr()))
+        return (info, st, llr, fst) if want_llr else (info, st)
+
+    def ldpc_decode(self, llr_rows, max_iterations, factor):
+        """llr_rows: float32 [n_cw, 648] in decoder order."""
+        n = llr_rows.shape[0]
+        assert llr_rows.dtype == torch.float32 and llr_rows.is_contiguous() and llr_rows.shape[1] == 648
+        nb = (self.geo.info_bits + 7) // 8
+        out = torch.empty((n, nb), dtype=torch.uint8, device=self.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=self.device)
+        it = torch.empty(n, dtype=torch.int16, device=self.device)
+        self._check(self.lib.ria_gpu_ldpc_decode_batch(self.h, _ptr(llr_rows), n, int(max_iterations), float(factor),
+                                                       _ptr(out), _ptr(ok), _ptr(it), _stream_ptr()))
+        return out, ok, it
+
+    def make_frames(self, seed, first_seq, n):
+        info = torch.empty((n, self.geo.info_bytes_per_frame), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_make_frames(self.h, int(seed), int(first_seq), n, _ptr(info), _stream_ptr()))
+        return info
+
+    def tx(self, info, peak=0.8):
+        n = info.shape[0]
+        assert info.dtype == torch.uint8 and info.is_contiguous() and info.shape[1] == self.geo.info_bytes_per_frame
+        s = torch.empty((n, self.geo.frame_samples), dtype=torch.float32, device=self.device)
+        self._check(self.lib.ria_gpu_tx_batch(self.h, _ptr(info), n, float(peak), _ptr(s), _stream_ptr()))
+        return s
+
+    def channel_(self, samples, kind, snr_db, seed, first_frame=0):
+        n = samples.shape[0]
+        assert samples.dtype == torch.float32 and samples.is_contiguous()
+        self._check(self.lib.ria_gpu_channel_batch(self.h, int(kind), float(snr_db), int(seed), int(first_frame),
+                                                   _ptr(samples), n, _stream_ptr()))
+        return samples
+
+    def debug_math(self, op, a, b=None):
+        out = torch.empty_like(a)
+        self._check(self.lib.ria_gpu_debug_math(self.h, op, _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream_ptr()))
+        return out
+
+    def frame_status(self, st):
+        return self._status_array(st, self.FRAME_STATUS)
+
+    def decode_status(self, st):
+        return self._status_array(st, self.DECODE_STATUS)

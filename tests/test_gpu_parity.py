@@ -1,0 +1,246 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on the same inputs and against the golden vectors recorded from the reference.
+Bit-exact for bytes, iteration counts and float32 bit patterns unless a tolerance is written here."""
+import ctypes
+import ctypes.util
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+FRAME_SETS = {"qam16_r12": ("QAM16", "R1_2"), "dqpsk_r12": ("DQPSK", "R1_2"), "qam64_r34": ("QAM64", "R3_4"),
+              "qam32_r34": ("QAM32", "R3_4"), "qpsk_r12": ("QPSK", "R1_2"), "dqpsk_r14": ("DQPSK", "R1_4"),
+              "qam16_r34": ("QAM16", "R3_4")}
+_engines = {}
+
+
+def engine(mod, rate):
+    import torch  # noqa: F401
+    from ria_amd.engine import RxEngine
+    key = (mod, rate)
+    if key not in _engines:
+        _engines[key] = RxEngine(mod, rate)
+    return _engines[key]
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_native_library_is_loaded():
+    from ria_amd import capi
+    L = capi.load()
+    assert L.ria_gpu_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libria_gpu.so" in f.read(), "the HIP extension must be the code that runs"
+
+
+@pytest.mark.parametrize("op,name", [(0, "sinf"), (1, "cosf"), (2, "logf"), (3, "atan2f"), (4, "hypotf")])
+def test_device_math_matches_glibc(op, name):
+    """devmath.h on the device vs the host libm the reference links (bit-exact)."""
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    fn = getattr(libm, name)
+    fn.restype = ctypes.c_float
+    rng = np.random.default_rng(op)
+    n = 60000
+    if op in (0, 1):
+        a = np.concatenate([rng.uniform(-7, 7, n // 2), rng.uniform(-119, 119, n // 4),
+                            rng.uniform(-1e-3, 1e-3, n // 4)]).astype(np.float32)
+        b = np.zeros_like(a)
+        fn.argtypes = [ctypes.c_float]
+        ref = np.array([fn(float(x)) for x in a], np.float32)
+    elif op == 2:
+        a = np.concatenate([rng.uniform(1e-30, 1, n // 2), np.exp(rng.uniform(-80, 80, n // 2))]).astype(np.float32)
+        b = np.zeros_like(a)
+        fn.argtypes = [ctypes.c_float]
+        ref = np.array([fn(float(x)) for x in a], np.float32)
+    else:
+        e = rng.uniform(-12, 12, (2, n))
+        a = (rng.normal(size=n) * np.exp(e[0])).astype(np.float32)
+        b = (rng.normal(size=n) * np.exp(e[1])).astype(np.float32)
+        fn.argtypes = [ctypes.c_float, ctypes.c_float]
+        ref = np.array([fn(float(x), float(y)) for x, y in zip(a, b)], np.float32)
+    e = engine("QAM16", "R1_2")
+    out = e.debug_math(op, dev(a), dev(b)).cpu().numpy()
+    bad = np.nonzero(bits(out) != bits(ref))[0]
+    assert len(bad) == 0, f"{name}: {len(bad)} mismatches, first a={a[bad[0]]!r} b={b[bad[0]]!r} gpu={out[bad[0]]!r} libm={ref[bad[0]]!r}"
+
+
+def test_ldpc_vectors_all_rates(golden):
+    g = golden("ldpc_vectors")
+    rates = {0: "R1_4", 2: "R1_2", 3: "R2_3", 4: "R3_4", 5: "R5_6"}
+    for r, rn in rates.items():
+        e = engine("QAM16", rn)
+        llr = dev(g[f"llr_{r}"])
+        nb = (e.geo.info_bits + 7) // 8
+        for c, (factor, mi) in enumerate(g["configs"]):
+            out, ok, it = e.ldpc_decode(llr, int(mi), float(factor))
+            ref = g[f"res_{r}"][:, c]
+            assert np.array_equal(ok.cpu().numpy(), ref[:, 0].astype(np.uint8)), f"rate {rn} cfg {c} success flags"
+            assert np.array_equal(it.cpu().numpy(), ref[:, 1].astype(np.int16)), f"rate {rn} cfg {c} iterations"
+            assert np.array_equal(out.cpu().numpy(), ref[:, 2:2 + nb].astype(np.uint8)), f"rate {rn} cfg {c} bytes"
+
+
+@pytest.mark.parametrize("name", list(FRAME_SETS))
+def test_demod_llrs_bit_exact_vs_reference_golden(golden, name):
+    g = golden("frames_" + name)
+    e = engine(*FRAME_SETS[name])
+    chan = g["chan"]
+    llr, st = e.demod(dev(g["rx"]), cfo_hz=chan[:, 2].astype(np.float32), abs_pos=chan[:, 3].astype(np.uint64))
+    llr = llr.cpu().numpy()
+    for f in range(len(llr)):
+        nd = int((bits(llr[f]) != bits(g["llr"][f])).sum())
+        assert nd == 0, f"{name} frame {f}: {nd} of {llr.shape[1]} LLRs differ from the reference"
+    s = e.frame_status(st)
+    aux = g["aux"]
+    for k, col in (("cfo_hz", 1), ("fading_index", 2), ("noise_variance", 3), ("lts_phase_slope", 4),
+                   ("snr_linear", 5), ("corr_phase", 6)):
+        assert np.array_equal(bits(s[k]), bits(aux[:, col])), k
+    assert np.allclose(s["snr_db"], aux[:, 0], rtol=1e-5, atol=1e-5)  # display value, log10f not bit-pinned
+
+
+@pytest.mark.parametrize("name", list(FRAME_SETS))
+def test_decode_fixed_frame_vs_reference_golden(golden, oracle, name):
+    g = golden("frames_" + name)
+    e = engine(*FRAME_SETS[name])
+    info, st = e.decode(dev(g["llr"]))
+    info = info.cpu().numpy()
+    s = e.decode_status(st)
+    for f in range(len(info)):
+        if s["needs_recovery"][f]:
+            continue  # host-side CRC recovery (frame_v2.cpp:1564-1880) is covered in test_host_recovery
+        assert np.array_equal(s["cw_ok"][f], g["dec_ok"][f]), f"{name} frame {f}: {s['cw_ok'][f]} vs {g['dec_ok'][f]}"
+        assert np.array_equal(info[f], g["dec_data"][f]), f"{name} frame {f}: payload bytes"
+        # iteration counts / attempts against the oracle restatement (the reference does not expose them)
+        d, ok, iters, att = oracle.decode_fixed_frame(g["llr"][f], int(g["rate"]), True, int(g["bps"]), flags=3)
+        assert np.array_equal(s["iterations"][f], iters.astype(np.uint16))
+        assert np.array_equal(s["attempts"][f], att.astype(np.uint8))
+
+
+def test_rx_fused_matches_oracle_random_frames(oracle):
+    """Seeded frames through oracle TX + oracle channel; GPU rx_batch vs oracle RX + decode."""
+    e = engine("QAM16", "R1_2")
+    rng = np.random.default_rng(7)
+    frames, infos = [], []
+    for f in range(24):
+        s, info, coded = oracle.tx_frame(po.QAM16, po.R1_2, rng.integers(0, 256, 141, dtype=np.uint8), f)
+        x = s * np.float32(0.8 / np.abs(s).max())
+        kind, snr = [(0, 18.0), (2, 22.0), (1, 16.0), (2, 18.0)][f % 4]
+        frames.append(oracle.channel(kind, snr, 900 + f, x))
+        infos.append(info)
+    info_g, st, llr_g, fst = e.rx(dev(np.stack(frames)), want_llr=True)
+    info_g, llr_g, s = info_g.cpu().numpy(), llr_g.cpu().numpy(), e.decode_status(st)
+    n_ok = 0
+    for f in range(24):
+        llr_o, aux = oracle.rx_process(po.QAM16, po.R1_2, frames[f])
+        assert np.array_equal(bits(llr_g[f]), bits(llr_o)), f"frame {f} LLRs"
+        d, ok, iters, att = oracle.decode_fixed_frame(llr_o, po.R1_2, True, 188, flags=3)
+        assert np.array_equal(s["cw_ok"][f], ok) and np.array_equal(info_g[f], d), f"frame {f} decode"
+        assert np.array_equal(s["iterations"][f], iters.astype(np.uint16))
+        if ok.all():
+            n_ok += 1
+            assert np.array_equal(info_g[f], infos[f]) and s["frame_valid"][f] == 1
+    assert n_ok >= 12
+
+
+@pytest.mark.parametrize("mod,rate", [("QAM16", "R1_2"), ("DQPSK", "R1_2"), ("QAM64", "R3_4"), ("QPSK", "R1_2"),
+                                      ("QAM32", "R3_4"), ("BPSK", "R1_2"), ("DBPSK", "R1_4")])
+def test_tx_samples_bit_exact_vs_oracle(oracle, mod, rate):
+    from ria_amd import capi
+    e = engine(mod, rate)
+    m, r = capi.MOD[mod], capi.RATE[rate]
+    rng = np.random.default_rng(3)
+    cap = e.geo.info_bytes_per_frame - 19
+    infos, ref = [], []
+    for f in range(3):
+        s, info, coded = oracle.tx_frame(m, r, rng.integers(0, 256, cap, dtype=np.uint8), 40 + f)
+        infos.append(info)
+        ref.append(s)
+    out = e.tx(dev(np.stack(infos)), peak=0.0).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(bits(out[f]), bits(ref[f])), f"{mod} {rate} frame {f}"
+    # peak normalisation as tools/test_waveform_simple.cpp:365-371
+    out = e.tx(dev(np.stack(infos)), peak=0.8).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(bits(out[f]), bits(ref[f] * np.float32(0.8 / np.abs(ref[f]).max())))
+
+
+def test_make_frames_are_valid_v2_frames(oracle):
+    e = engine("QAM16", "R1_2")
+    info = e.make_frames(seed=11, first_seq=65530, n=16).cpu().numpy()
+    for f in range(16):
+        fr = info[f]
+        assert fr[0] == 0x55 and fr[1] == 0x4C and fr[2] == 0x30 and fr[12] == 4
+        assert ((fr[4] << 8) | fr[5]) == (65530 + f) & 0xFFFF
+        plen = (fr[13] << 8) | fr[14]
+        assert plen == 141
+        assert oracle.lib.ro_crc16(po.up(fr), 15) == (fr[15] << 8) | fr[16]
+        assert oracle.lib.ro_crc16(po.up(fr), 158) == (fr[158] << 8) | fr[159]
+        ref = oracle.make_frame(fr[17:17 + plen], (65530 + f) & 0xFFFF, po.R1_2)
+        assert np.array_equal(ref, fr)
+    assert len({bytes(x) for x in info[:, 17:158]}) == 16
+
+
+def test_loopback_round_trip_full_size():
+    """Size-independent property at bench scale: make_frames -> tx -> AWGN 20 dB -> rx returns the
+    transmitted bytes for (nearly) every frame, and frame_valid agrees with byte equality."""
+    e = engine("QAM16", "R1_2")
+    n = 4096
+    info = e.make_frames(seed=5, first_seq=0, n=n)
+    x = e.tx(info, peak=0.8)
+    e.channel_(x, kind=0, snr_db=20.0, seed=99)
+    out, st = e.rx(x)
+    s = e.decode_status(st)
+    same = (out == info).all(dim=1).cpu().numpy()
+    assert same.mean() > 0.98, same.mean()
+    assert np.array_equal(s["frame_valid"].astype(bool) & s["cw_ok"].all(axis=1), same)
+
+
+def test_channel_statistics():
+    """Statistical parity with sim::WattersonChannel (hf_channel.hpp): noise power from the SNR
+    definition (rms of non-zero samples), unit mean fading power, delayed second tap."""
+    import torch
+    e = engine("QAM16", "R1_2")
+    n, L = 256, e.geo.frame_samples
+    t = torch.arange(L, device="cuda", dtype=torch.float32)
+    x0 = (0.3 * torch.sin(2 * np.pi * 1500.0 * t / 48000.0)).repeat(n, 1).contiguous()
+    y = e.channel_(x0.clone(), kind=0, snr_db=10.0, seed=1)
+    noise = (y - x0)
+    rms = float(x0[0].pow(2).mean().sqrt())
+    assert abs(float(noise.std()) / (rms * 10 ** (-10 / 20)) - 1) < 0.02
+    assert abs(float(noise.mean())) < 2e-3
+    # fading: disable noise by a huge SNR, measure mean output power vs two equal-gain Rayleigh paths
+    y = e.channel_(x0.clone(), kind=2, snr_db=200.0, seed=2)
+    # frames start with fading state (1,0) and relax with time constant 1/alpha = 15279 samples
+    p_out = float(y[:, L // 2:].pow(2).mean()) / float(x0[:, L // 2:].pow(2).mean())
+    assert 0.5 < p_out < 2.0, p_out
+    # independent frames, deterministic in (seed, frame index)
+    y2 = e.channel_(x0.clone(), kind=2, snr_db=200.0, seed=2)
+    assert torch.equal(y, y2)
+    y3 = e.channel_(x0[:8].clone(), kind=2, snr_db=200.0, seed=2, first_frame=8)
+    assert torch.equal(y3, y[8:16])
+
+
+def test_edge_cases():
+    import torch
+    e = engine("QAM16", "R1_2")
+    # empty batch
+    info, st = e.rx(torch.empty((0, e.geo.frame_samples), dtype=torch.float32, device="cuda"))
+    assert info.shape[0] == 0
+    # all-zero frame: no NaNs in LLRs, nothing decodes as a valid frame
+    z = torch.zeros((2, e.geo.frame_samples), dtype=torch.float32, device="cuda")
+    info, st, llr, fst = e.rx(z, want_llr=True)
+    s = e.decode_status(st)
+    assert not s["frame_valid"].any()
+    # saturated LLRs decode instantly with 0 iterations
+    cw = torch.full((4, 648), 20.0, device="cuda")
+    out, ok, it = e.ldpc_decode(cw, 80, 0.9375)
+    assert ok.all() and (it == 0).all() and (out == 0).all()
