@@ -60,6 +60,10 @@ def load(build_if_needed=True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (soname libamdhip64.so.7).  Import it first so that this
+    # process holds ONE runtime: libria_gpu.so's DT_NEEDED then resolves to the copy torch loaded,
+    # and device pointers / streams from torch are valid inside the library.
+    import torch  # noqa: F401
     path = _build.build() if build_if_needed else _build.LIB
     if not os.path.exists(path):
         raise RuntimeError("libria_gpu.so is missing: run `python -m ria_amd.build`")

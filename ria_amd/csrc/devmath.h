@@ -47,21 +47,23 @@ RIA_HD double dfma(double a, double b, double c) {
 }
 RIA_HD double dsqrt(double a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __dsqrt_rn(a);
+    return __builtin_sqrt(a);
 #else
     return sqrt(a);
 #endif
 }
 RIA_HD float fsqrt(float a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(a);
+    // NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS that is the 1-ulp native sqrt.
+    // __builtin_sqrtf is IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt (build flag).
+    return __builtin_sqrtf(a);
 #else
     return sqrtf(a);
 #endif
 }
 RIA_HD float fdiv(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __fdiv_rn(a, b);
+    return a / b;  // IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt
 #else
     return a / b;
 #endif

@@ -1,0 +1,252 @@
+// ria_amd/csrc/frame_recovery.hpp — host half of v2::decodeFixedFrame: frame reassembly, CRC
+// verification and the "LDPC false positive" recovery (src/protocol/frame_v2.cpp:1564-1880).
+//
+// This is byte-level control logic that touches ~1 % of frames (all four codewords converged but the
+// frame CRC fails), so it stays on the host like the rest of src/protocol; the LDPC re-decodes it
+// needs are done on the GPU beforehand (16 per flagged frame, batched) and passed in.
+// Product code, independent of oracle/.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace ria {
+
+struct Crc16Tables {
+    std::vector<uint16_t> bit;   // delta of the bit at distance q from the end of the message
+    std::vector<uint16_t> init;  // CRC (init 0xFFFF) of L zero bytes
+    static uint16_t slow(const uint8_t* d, int n, uint16_t init) {  // frame_v2.cpp:115-128
+        uint16_t crc = init;
+        for (int i = 0; i < n; ++i) {
+            crc ^= static_cast<uint16_t>(d[i]) << 8;
+            for (int j = 0; j < 8; ++j)
+                crc = (crc & 0x8000) ? static_cast<uint16_t>((crc << 1) ^ 0x1021) : static_cast<uint16_t>(crc << 1);
+        }
+        return crc;
+    }
+    void build(int max_bytes) {
+        bit.resize(static_cast<size_t>(max_bytes) * 8 + 16);
+        init.resize(static_cast<size_t>(max_bytes) + 2);
+        // x^(q+16) mod P by shifting: delta[q+1] = delta[q] * x
+        uint16_t v = slow(reinterpret_cast<const uint8_t*>("\x01"), 1, 0);
+        for (size_t q = 0; q < bit.size(); ++q) {
+            bit[q] = v;
+            v = (v & 0x8000) ? static_cast<uint16_t>((v << 1) ^ 0x1021) : static_cast<uint16_t>(v << 1);
+        }
+        std::vector<uint8_t> z(init.size(), 0);
+        uint16_t c = 0xFFFF;
+        for (size_t L = 0; L < init.size(); ++L) {
+            init[L] = c;
+            uint8_t zero = 0;
+            c = slow(&zero, 1, c);
+        }
+    }
+    uint16_t crc(const uint8_t* d, int L) const {
+        uint16_t acc = init[L];
+        for (int i = 0; i < L; ++i) {
+            int b = d[i], q0 = (L - 1 - i) * 8;
+            while (b) { int t = __builtin_ctz(b); b &= b - 1; acc ^= bit[q0 + t]; }
+        }
+        return acc;
+    }
+};
+
+struct FrameRecovery {
+    const Crc16Tables& T;
+    int bpc;  // info bytes per codeword
+    explicit FrameRecovery(const Crc16Tables& t, int bytes_per_cw) : T(t), bpc(bytes_per_cw) {}
+
+    bool parse_header(const uint8_t* d, int len, bool* ctl, int* plen) const {  // frame_v2.cpp:1195-1252
+        if (len < 20) return false;
+        if (d[0] != 0x55 || d[1] != 0x4C) return false;
+        int t = d[2];
+        *ctl = (t == 0x10 || t == 0x11 || t == 0x16 || t == 0x17 || t == 0x20 || t == 0x21 || t == 0x15 || t == 0x40);
+        if (*ctl) {
+            if (T.crc(d, 18) != static_cast<uint16_t>((d[18] << 8) | d[19])) return false;
+            *plen = 0;
+        } else {
+            *plen = (d[13] << 8) | d[14];
+            if (T.crc(d, 15) != static_cast<uint16_t>((d[15] << 8) | d[16])) return false;
+        }
+        return true;
+    }
+    // CodewordStatus::reassemble + reassembleCodewords (frame_v2.cpp:1030-1063, :959-989), all CWs decoded
+    int reassemble(const uint8_t cw[4][68], uint8_t* out) const {
+        bool ctl; int plen;
+        if (!parse_header(cw[0], bpc, &ctl, &plen)) return 0;
+        int expected = ctl ? 20 : 17 + plen + 2, n = 0;
+        for (int i = 0; i < 4; ++i) {
+            int remaining = expected - n;
+            if (remaining == 0) break;
+            if (i == 0 || cw[i][0] != 0xD5) { int c = std::min(remaining, bpc); std::memcpy(out + n, cw[i], c); n += c; }
+            else { int c = std::min(remaining, bpc - 2); std::memcpy(out + n, cw[i] + 2, c); n += c; }
+        }
+        return n;
+    }
+    bool verify(const uint8_t* d, int len) const {  // verifyFrame lambda, frame_v2.cpp:1583-1589
+        bool ctl; int plen;
+        if (len == 0 || !parse_header(d, len, &ctl, &plen)) return false;
+        if (ctl) return true;
+        int sz = 17 + plen + 2;
+        if (len < sz) return false;
+        return T.crc(d, sz - 2) == static_cast<uint16_t>((d[sz - 2] << 8) | d[sz - 1]);
+    }
+    bool frame_valid(const uint8_t cw[4][68]) const {
+        uint8_t fd[4 * 68];
+        int n = reassemble(cw, fd);
+        return verify(fd, n);
+    }
+
+    struct Suspect { int frame_bit; float abs_llr; };
+    // libstdc++ std::sort (introsort, insertion threshold 16) with comparator a.abs_llr < b.abs_llr:
+    // the order of equal keys decides which suspects are tried first (frame_v2.cpp:1717-1718).
+    static bool lt(const Suspect& a, const Suspect& b) { return a.abs_llr < b.abs_llr; }
+    static void linear_insert(Suspect* last) {
+        Suspect val = *last;
+        Suspect* next = last - 1;
+        while (lt(val, *next)) { *last = *next; last = next; --next; }
+        *last = val;
+    }
+    static void insertion(Suspect* first, Suspect* last) {
+        if (first == last) return;
+        for (Suspect* i = first + 1; i != last; ++i) {
+            if (lt(*i, *first)) { Suspect v = *i; std::memmove(first + 1, first, (i - first) * sizeof(Suspect)); *first = v; }
+            else linear_insert(i);
+        }
+    }
+    static void introsort(Suspect* first, Suspect* last, int depth) {
+        while (last - first > 16) {
+            if (depth == 0) { std::make_heap(first, last, lt); std::sort_heap(first, last, lt); return; }
+            --depth;
+            Suspect *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1;
+            if (lt(*a, *b)) { if (lt(*b, *c)) std::swap(*first, *b); else if (lt(*a, *c)) std::swap(*first, *c); else std::swap(*first, *a); }
+            else { if (lt(*a, *c)) std::swap(*first, *a); else if (lt(*b, *c)) std::swap(*first, *c); else std::swap(*first, *b); }
+            Suspect *lo = first + 1, *hi = last;
+            for (;;) {
+                while (lt(*lo, *first)) ++lo;
+                --hi;
+                while (lt(*first, *hi)) --hi;
+                if (!(lo < hi)) break;
+                std::swap(*lo, *hi);
+                ++lo;
+            }
+            introsort(lo, last, depth);
+            last = lo;
+        }
+    }
+    static void sort_suspects(std::vector<Suspect>& v) {
+        int n = static_cast<int>(v.size());
+        if (n == 0) return;
+        int lg = 0;
+        for (int t = n; t > 1; t >>= 1) ++lg;
+        introsort(v.data(), v.data() + n, 2 * lg);
+        if (n > 16) { insertion(v.data(), v.data() + 16); for (Suspect* i = v.data() + 16; i != v.data() + n; ++i) linear_insert(i); }
+        else insertion(v.data(), v.data() + n);
+    }
+
+    // cw: the four decoded codeword payloads (modified in place when recovered).
+    // cwllr: [4][648] decoder-order LLRs.  redec_ok/redec: results of re-decoding each codeword with
+    // factors {0.75, 0.625, 0.5, 0.875} (attempt-major: [attempt][cw]).
+    // Returns true if the frame was recovered (cw now verifies), false -> all codewords are failures.
+    bool recover(uint8_t cw[4][68], const float* cwllr, const uint8_t redec_ok[4][4], const uint8_t redec[4][4][68]) const {
+        uint8_t fd[4 * 68], trial[4 * 68];
+        int flen = reassemble(cw, fd);
+        bool recovered = false;
+        auto hdr_ok = [&]() {
+            return cw[0][0] == 0x55 && cw[0][1] == 0x4C && T.crc(cw[0], 15) == static_cast<uint16_t>((cw[0][15] << 8) | cw[0][16]);
+        };
+        if (flen == 0) {  // case 1: header CRC error in CW0
+            for (int by = 0; by < bpc && !recovered; ++by)
+                for (int bit = 0; bit < 8 && !recovered; ++bit) {
+                    cw[0][by] ^= static_cast<uint8_t>(1 << bit);
+                    if (hdr_ok()) { int tl = reassemble(cw, trial); if (verify(trial, tl)) recovered = true; }
+                    if (!recovered) cw[0][by] ^= static_cast<uint8_t>(1 << bit);
+                }
+            if (!recovered) {
+                int tb = bpc * 8;
+                for (int b1 = 0; b1 < tb && !recovered; ++b1) {
+                    cw[0][b1 / 8] ^= static_cast<uint8_t>(1 << (b1 % 8));
+                    for (int b2 = b1 + 1; b2 < tb && !recovered; ++b2) {
+                        cw[0][b2 / 8] ^= static_cast<uint8_t>(1 << (b2 % 8));
+                        if (hdr_ok()) { int tl = reassemble(cw, trial); if (verify(trial, tl)) recovered = true; }
+                        if (!recovered) cw[0][b2 / 8] ^= static_cast<uint8_t>(1 << (b2 % 8));
+                    }
+                    if (!recovered) cw[0][b1 / 8] ^= static_cast<uint8_t>(1 << (b1 % 8));
+                }
+            }
+        } else {  // case 2: frame CRC error
+            bool ctl; int plen;
+            if (parse_header(fd, flen, &ctl, &plen) && !ctl) {
+                int expected = 17 + plen + 2;
+                if (flen >= expected) {
+                    uint16_t stored = static_cast<uint16_t>((fd[expected - 2] << 8) | fd[expected - 1]);
+                    int data_bytes = expected - 2, data_bits = data_bytes * 8;
+                    uint16_t orig = T.crc(fd, data_bytes), syn = stored ^ orig;
+                    auto delta = [&](int p) { return T.bit[(data_bytes - 1 - p / 8) * 8 + (p % 8)]; };
+                    auto fix = [&](int p) { int fb = p / 8, c = fb / bpc; if (c < 4) cw[c][fb % bpc] ^= static_cast<uint8_t>(1 << (p % 8)); };
+                    for (int p = 0; p < data_bits && !recovered; ++p)
+                        if (delta(p) == syn) { int fb = p / 8; if (fb / bpc < 4) { fix(p); recovered = true; } }
+                    if (!recovered)
+                        for (int bit = 0; bit < 16 && !recovered; ++bit)
+                            if (syn == (1u << bit)) {
+                                int fb = (bit >= 8) ? expected - 2 : expected - 1, c = fb / bpc;
+                                if (c < 4) { cw[c][fb % bpc] ^= static_cast<uint8_t>(1 << (bit % 8)); recovered = true; }
+                            }
+                    std::vector<Suspect> sus;
+                    for (int c = 0; c < 4; ++c)
+                        for (int i = 0; i < bpc * 8 && i < 648; ++i) {
+                            int fbit = c * bpc * 8 + i;
+                            if (fbit / 8 >= data_bytes) continue;
+                            float l = cwllr[c * 648 + i];
+                            int chb = l < 0, db = (cw[c][i / 8] >> (i % 8)) & 1;
+                            if (chb != db) sus.push_back({fbit, std::fabs(l)});
+                        }
+                    sort_suspects(sus);
+                    int ns = std::min<int>(30, static_cast<int>(sus.size()));
+                    uint16_t sd[30];
+                    for (int i = 0; i < ns; ++i) sd[i] = delta(sus[i].frame_bit);
+                    auto try_set = [&](std::initializer_list<int> idx) {
+                        for (int i : idx) fix(sus[i].frame_bit);
+                        int tl = reassemble(cw, trial);
+                        if (verify(trial, tl)) { recovered = true; return; }
+                        for (int i : idx) fix(sus[i].frame_bit);
+                    };
+                    if (!recovered)
+                        for (int a = 0; a < ns && !recovered; ++a)
+                            for (int b = a + 1; b < ns && !recovered; ++b)
+                                if (static_cast<uint16_t>(sd[a] ^ sd[b]) == syn) try_set({a, b});
+                    if (!recovered)
+                        for (int a = 0; a < ns && !recovered; ++a)
+                            for (int b = a + 1; b < ns && !recovered; ++b)
+                                for (int c = b + 1; c < ns && !recovered; ++c)
+                                    if (static_cast<uint16_t>(sd[a] ^ sd[b] ^ sd[c]) == syn) try_set({a, b, c});
+                    if (!recovered) {
+                        int n4 = std::min(ns, 15);
+                        for (int a = 0; a < n4 && !recovered; ++a)
+                            for (int b = a + 1; b < n4 && !recovered; ++b)
+                                for (int c = b + 1; c < n4 && !recovered; ++c)
+                                    for (int d = c + 1; d < n4 && !recovered; ++d)
+                                        if (static_cast<uint16_t>(sd[a] ^ sd[b] ^ sd[c] ^ sd[d]) == syn) try_set({a, b, c, d});
+                    }
+                }
+            }
+        }
+        if (!recovered) {  // fallback: re-decode with other min-sum factors (frame_v2.cpp:1836-1866)
+            for (int at = 0; at < 4 && !recovered; ++at)
+                for (int c = 0; c < 4 && !recovered; ++c) {
+                    if (!redec_ok[at][c] || std::memcmp(redec[at][c], cw[c], bpc) == 0) continue;
+                    uint8_t orig[68];
+                    std::memcpy(orig, cw[c], bpc);
+                    std::memcpy(cw[c], redec[at][c], bpc);
+                    int tl = reassemble(cw, trial);
+                    if (verify(trial, tl)) recovered = true;
+                    else std::memcpy(cw[c], orig, bpc);
+                }
+        }
+        return recovered;
+    }
+};
+
+}  // namespace ria

@@ -11,6 +11,7 @@
 
 #include "../../include/ria_gpu.h"
 #include "host_tables.hpp"
+#include "frame_recovery.hpp"
 #include "ldpc_kernels.hip.h"
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
@@ -34,6 +35,7 @@ struct ria_gpu {
     // workspace
     float* d_llr_ws = nullptr;            // max_batch * llrs_per_frame (fused path)
     LdpcDev ldpc_dev{};
+    Crc16Tables crc;
 };
 
 namespace {
@@ -72,6 +74,98 @@ uint16_t crc16_host(const uint8_t* d, int n, uint16_t init) {  // frame_v2.cpp:1
 }
 
 }  // namespace
+
+// ---- CRC-guided false-positive recovery glue (host logic in frame_recovery.hpp) -----------------
+__global__ void gather_rows_kernel(const float* __restrict__ llr, int stride, const int* __restrict__ frame_idx,
+                                   const uint16_t* __restrict__ gather, float* __restrict__ rows) {
+    int f = blockIdx.x >> 2, cw = blockIdx.x & 3;
+    const float* src = llr + static_cast<size_t>(frame_idx[f]) * stride;
+    for (int i = threadIdx.x; i < 648; i += blockDim.x)
+        rows[static_cast<size_t>(blockIdx.x) * 648 + i] = src[gather[cw * 648 + i]];
+}
+__global__ void scatter_results_kernel(const int* __restrict__ frame_idx, const uint8_t* __restrict__ info_c,
+                                       const ria_decode_status* __restrict__ st_c, int info_bytes,
+                                       uint8_t* __restrict__ info_out, ria_decode_status* __restrict__ st_out) {
+    int f = blockIdx.x, dst = frame_idx[f];
+    for (int i = threadIdx.x; i < info_bytes; i += blockDim.x)
+        info_out[static_cast<size_t>(dst) * info_bytes + i] = info_c[static_cast<size_t>(f) * info_bytes + i];
+    if (threadIdx.x == 0) st_out[dst] = st_c[f];
+}
+
+// Runs after decode_frames_kernel when RIA_DECODE_CRC_RECOVER is set.  Synchronises the stream.
+static int run_crc_recovery(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
+                            uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s) {
+    std::vector<ria_decode_status> st(n_frames);
+    HIP_TRY(h, hipMemcpyAsync(st.data(), status_dev, sizeof(ria_decode_status) * n_frames, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<int> idx;
+    for (int f = 0; f < n_frames; ++f) if (st[f].needs_recovery) idx.push_back(f);
+    if (idx.empty()) return RIA_OK;
+    const int nf = static_cast<int>(idx.size()), bpc = h->geo.bytes_per_codeword, ib = h->geo.info_bytes_per_frame;
+    const int nb = (h->geo.info_bits + 7) / 8;
+    int* d_idx = nullptr; float* d_rows = nullptr; uint8_t* d_out = nullptr; uint8_t* d_ok = nullptr; uint16_t* d_it = nullptr;
+    uint8_t* d_info_c = nullptr; ria_decode_status* d_st_c = nullptr;
+    auto cleanup = [&]() { for (void* p_ : {(void*)d_idx, (void*)d_rows, (void*)d_out, (void*)d_ok, (void*)d_it, (void*)d_info_c, (void*)d_st_c}) (void)hipFree(p_); };
+#define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    const int ncw = nf * 4;
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), nf * sizeof(int)));
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), static_cast<size_t>(ncw) * 648 * sizeof(float)));
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), static_cast<size_t>(4) * ncw * nb));
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_ok), static_cast<size_t>(4) * ncw));
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_it), static_cast<size_t>(4) * ncw * sizeof(uint16_t)));
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_info_c), static_cast<size_t>(nf) * ib));
+    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_st_c), static_cast<size_t>(nf) * sizeof(ria_decode_status)));
+    R_TRY(hipMemcpyAsync(d_idx, idx.data(), nf * sizeof(int), hipMemcpyHostToDevice, s));
+    const uint16_t* gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ncw), dim3(128), 0, s, llr_dev, llr_stride, d_idx, gather, d_rows);
+    static const float rf[4] = {0.75f, 0.625f, 0.5f, 0.875f};  // frame_v2.cpp:1837
+    int lds = 4 * ldpc_wave_lds_bytes(h->ldpc_dev.m);
+    for (int at = 0; at < 4; ++at)
+        hipLaunchKernelGGL(ldpc_decode_rows_kernel, dim3((ncw + 3) / 4), dim3(256), lds, s, h->ldpc_dev, d_rows, ncw,
+                           h->geo.ldpc_max_iterations, rf[at], d_out + static_cast<size_t>(at) * ncw * nb,
+                           d_ok + static_cast<size_t>(at) * ncw, d_it + static_cast<size_t>(at) * ncw);
+    R_TRY(hipGetLastError());
+    std::vector<float> rows(static_cast<size_t>(ncw) * 648);
+    std::vector<uint8_t> out(static_cast<size_t>(4) * ncw * nb), ok(static_cast<size_t>(4) * ncw), info_c(static_cast<size_t>(nf) * ib);
+    std::vector<ria_decode_status> st_c(nf);
+    R_TRY(hipMemcpyAsync(rows.data(), d_rows, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(ok.data(), d_ok, ok.size(), hipMemcpyDeviceToHost, s));
+    for (int i = 0; i < nf; ++i)
+        R_TRY(hipMemcpyAsync(info_c.data() + static_cast<size_t>(i) * ib, info_out_dev + static_cast<size_t>(idx[i]) * ib, ib,
+                             hipMemcpyDeviceToHost, s));
+    R_TRY(hipStreamSynchronize(s));
+    FrameRecovery rec(h->crc, bpc);
+    for (int i = 0; i < nf; ++i) {
+        uint8_t cw[4][68], rd[4][4][68], rok[4][4];
+        std::memset(cw, 0, sizeof(cw));
+        for (int c = 0; c < 4; ++c) std::memcpy(cw[c], info_c.data() + static_cast<size_t>(i) * ib + c * bpc, bpc);
+        for (int at = 0; at < 4; ++at)
+            for (int c = 0; c < 4; ++c) {
+                size_t r = static_cast<size_t>(at) * ncw + static_cast<size_t>(i) * 4 + c;
+                rok[at][c] = ok[r];
+                std::memcpy(rd[at][c], out.data() + r * nb, bpc);
+            }
+        bool good = rec.recover(cw, rows.data() + static_cast<size_t>(i) * 4 * 648, rok, rd);
+        ria_decode_status sn = st[idx[i]];
+        sn.needs_recovery = 0;
+        sn.frame_valid = good ? 1 : 0;
+        for (int c = 0; c < 4; ++c) {
+            sn.cw_ok[c] = good ? 1 : 0;
+            if (good) std::memcpy(info_c.data() + static_cast<size_t>(i) * ib + c * bpc, cw[c], bpc);
+            else std::memset(info_c.data() + static_cast<size_t>(i) * ib + c * bpc, 0, bpc);
+        }
+        st_c[i] = sn;
+    }
+    R_TRY(hipMemcpyAsync(d_info_c, info_c.data(), info_c.size(), hipMemcpyHostToDevice, s));
+    R_TRY(hipMemcpyAsync(d_st_c, st_c.data(), st_c.size() * sizeof(ria_decode_status), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(nf), dim3(64), 0, s, d_idx, d_info_c, d_st_c, ib, info_out_dev, status_dev);
+    R_TRY(hipGetLastError());
+    R_TRY(hipStreamSynchronize(s));
+#undef R_TRY
+    cleanup();
+    return RIA_OK;
+}
 
 extern "C" {
 
@@ -166,6 +260,7 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
         CREATE_TRY(upload(&h->d_crc_bit, bit));
         CREATE_TRY(upload(&h->d_crc_init, init));
     }
+    h->crc.build(4 * 68);
     CREATE_TRY(upload(&h->d_twiddle, build_twiddles()));
     CREATE_TRY(upload(&h->d_nco, build_nco_table(g.frame_samples)));
     {
@@ -240,12 +335,14 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
 
 int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
                          uint8_t* info_out_dev, ria_decode_status* status_dev, void* stream) {
+    if (h && n_frames == 0) return RIA_OK;
     if (!h || !llr_dev || !info_out_dev || !status_dev || n_frames < 0 || llr_stride < kFrameBits)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_decode_batch: bad argument (llr_stride must be >= 2592)");
-    if (n_frames == 0) return RIA_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     launch_decode(h, llr_dev, llr_stride, n_frames, flags, info_out_dev, status_dev, static_cast<hipStream_t>(stream));
     HIP_TRY(h, hipGetLastError());
+    if (flags & RIA_DECODE_CRC_RECOVER)
+        return run_crc_recovery(h, llr_dev, llr_stride, n_frames, flags, info_out_dev, status_dev, static_cast<hipStream_t>(stream));
     return RIA_OK;
 }
 
@@ -253,9 +350,9 @@ int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride,
 int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
                         const ria_frame_meta* meta_dev, int n_frames, float* llr_out_dev,
                         ria_frame_status* status_dev, void* stream) {
+    if (h && n_frames == 0) return RIA_OK;
     if (!h || !samples_dev || !llr_out_dev || n_frames < 0)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_demod_batch: bad argument");
-    if (n_frames == 0) return RIA_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     DemodArgs A;
     A.k = static_cast<const DemodConst*>(h->d_demod_const);
@@ -277,6 +374,7 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
                      const ria_frame_meta* meta_dev, int n_frames, uint32_t flags, uint8_t* info_out_dev,
                      ria_decode_status* decode_status_dev, float* llr_out_dev, ria_frame_status* demod_status_dev,
                      void* stream) {
+    if (h && n_frames == 0) return RIA_OK;
     if (!h || !samples_dev || !info_out_dev || !decode_status_dev || n_frames < 0)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_rx_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -294,6 +392,12 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
         launch_decode(h, llr, h->geo.llrs_per_frame, nb, flags,
                       info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame, decode_status_dev + done, s);
         HIP_TRY(h, hipGetLastError());
+        if (flags & RIA_DECODE_CRC_RECOVER) {
+            rc = run_crc_recovery(h, llr, h->geo.llrs_per_frame, nb, flags,
+                                  info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame,
+                                  decode_status_dev + done, s);
+            if (rc != RIA_OK) return rc;
+        }
         done += nb;
     }
     return RIA_OK;

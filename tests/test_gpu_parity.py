@@ -31,6 +31,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def torch_idx(mask):
+    import torch
+    return torch.from_numpy(np.nonzero(mask)[0]).cuda()
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -43,14 +48,22 @@ def test_native_library_is_loaded():
         assert "libria_gpu.so" in f.read(), "the HIP extension must be the code that runs"
 
 
-@pytest.mark.parametrize("op,name", [(0, "sinf"), (1, "cosf"), (2, "logf"), (3, "atan2f"), (4, "hypotf")])
+@pytest.mark.parametrize("op,name", [(0, "sinf"), (1, "cosf"), (2, "logf"), (3, "atan2f"), (4, "hypotf"),
+                                     (5, "div"), (6, "sqrtf")])
 def test_device_math_matches_glibc(op, name):
     """devmath.h on the device vs the host libm the reference links (bit-exact)."""
+    rng = np.random.default_rng(op)
+    n = 60000
+    if op >= 5:  # IEEE division / square root: numpy float32 is correctly rounded
+        a = np.exp(rng.uniform(-40, 40, n)).astype(np.float32)
+        b = (np.exp(rng.uniform(-40, 40, n)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+        ref = (a / b) if op == 5 else np.sqrt(a)
+        out = engine("QAM16", "R1_2").debug_math(op, dev(a), dev(b)).cpu().numpy()
+        assert np.array_equal(bits(out), bits(ref))
+        return
     libm = ctypes.CDLL(ctypes.util.find_library("m"))
     fn = getattr(libm, name)
     fn.restype = ctypes.c_float
-    rng = np.random.default_rng(op)
-    n = 60000
     if op in (0, 1):
         a = np.concatenate([rng.uniform(-7, 7, n // 2), rng.uniform(-119, 119, n // 4),
                             rng.uniform(-1e-3, 1e-3, n // 4)]).astype(np.float32)
@@ -114,13 +127,12 @@ def test_decode_fixed_frame_vs_reference_golden(golden, oracle, name):
     info, st = e.decode(dev(g["llr"]))
     info = info.cpu().numpy()
     s = e.decode_status(st)
+    assert not s["needs_recovery"].any()  # RIA_DECODE_FULL finishes the CRC recovery (frame_v2.cpp:1564-1880)
     for f in range(len(info)):
-        if s["needs_recovery"][f]:
-            continue  # host-side CRC recovery (frame_v2.cpp:1564-1880) is covered in test_host_recovery
         assert np.array_equal(s["cw_ok"][f], g["dec_ok"][f]), f"{name} frame {f}: {s['cw_ok'][f]} vs {g['dec_ok'][f]}"
         assert np.array_equal(info[f], g["dec_data"][f]), f"{name} frame {f}: payload bytes"
         # iteration counts / attempts against the oracle restatement (the reference does not expose them)
-        d, ok, iters, att = oracle.decode_fixed_frame(g["llr"][f], int(g["rate"]), True, int(g["bps"]), flags=3)
+        d, ok, iters, att = oracle.decode_fixed_frame(g["llr"][f], int(g["rate"]), True, int(g["bps"]), flags=7)
         assert np.array_equal(s["iterations"][f], iters.astype(np.uint16))
         assert np.array_equal(s["attempts"][f], att.astype(np.uint8))
 
@@ -142,9 +154,10 @@ def test_rx_fused_matches_oracle_random_frames(oracle):
     for f in range(24):
         llr_o, aux = oracle.rx_process(po.QAM16, po.R1_2, frames[f])
         assert np.array_equal(bits(llr_g[f]), bits(llr_o)), f"frame {f} LLRs"
-        d, ok, iters, att = oracle.decode_fixed_frame(llr_o, po.R1_2, True, 188, flags=3)
+        d, ok, iters, att = oracle.decode_fixed_frame(llr_o, po.R1_2, True, 188, flags=7)
         assert np.array_equal(s["cw_ok"][f], ok) and np.array_equal(info_g[f], d), f"frame {f} decode"
         assert np.array_equal(s["iterations"][f], iters.astype(np.uint16))
+        assert np.array_equal(s["attempts"][f], att.astype(np.uint8))
         if ok.all():
             n_ok += 1
             assert np.array_equal(info_g[f], infos[f]) and s["frame_valid"][f] == 1
@@ -179,13 +192,15 @@ def test_make_frames_are_valid_v2_frames(oracle):
     for f in range(16):
         fr = info[f]
         assert fr[0] == 0x55 and fr[1] == 0x4C and fr[2] == 0x30 and fr[12] == 4
+        fr = fr.astype(np.int64)
         assert ((fr[4] << 8) | fr[5]) == (65530 + f) & 0xFFFF
         plen = (fr[13] << 8) | fr[14]
         assert plen == 141
-        assert oracle.lib.ro_crc16(po.up(fr), 15) == (fr[15] << 8) | fr[16]
-        assert oracle.lib.ro_crc16(po.up(fr), 158) == (fr[158] << 8) | fr[159]
-        ref = oracle.make_frame(fr[17:17 + plen], (65530 + f) & 0xFFFF, po.R1_2)
-        assert np.array_equal(ref, fr)
+        fb = info[f]
+        assert oracle.lib.ro_crc16(po.up(fb), 15) == (fr[15] << 8) | fr[16]
+        assert oracle.lib.ro_crc16(po.up(fb), 158) == (fr[158] << 8) | fr[159]
+        ref = oracle.make_frame(fb[17:17 + plen], (65530 + f) & 0xFFFF, po.R1_2)
+        assert np.array_equal(ref, fb)
     assert len({bytes(x) for x in info[:, 17:158]}) == 16
 
 
@@ -197,11 +212,25 @@ def test_loopback_round_trip_full_size():
     info = e.make_frames(seed=5, first_seq=0, n=n)
     x = e.tx(info, peak=0.8)
     e.channel_(x, kind=0, snr_db=20.0, seed=99)
-    out, st = e.rx(x)
+    from ria_amd import capi
+    out, st = e.rx(x, flags=capi.DECODE_PHASE0 | capi.DECODE_PERTURB)
     s = e.decode_status(st)
     same = (out == info).all(dim=1).cpu().numpy()
     assert same.mean() > 0.98, same.mean()
-    assert np.array_equal(s["frame_valid"].astype(bool) & s["cw_ok"].all(axis=1), same)
+    # frames whose CW1..3 starts with 0xD5 take the reference's marker-stripping reassembly quirk
+    # (frame_v2.cpp:959-989): the kernel flags them for the host recovery path instead of validating
+    quirk = s["reserved"][:, 0].astype(bool)
+    assert 0 < quirk.sum() < n * 0.03
+    assert np.array_equal((s["frame_valid"].astype(bool) | quirk) & s["cw_ok"].all(axis=1), same)
+    assert np.array_equal(s["needs_recovery"].astype(bool), s["cw_ok"].all(axis=1) & ~s["frame_valid"].astype(bool))
+    # full decodeFixedFrame semantics: the reference fails those frames (the stripped frame cannot pass CRC)
+    out7, st7 = e.rx(x)
+    s7 = e.decode_status(st7)
+    assert not s7["needs_recovery"].any()
+    ok7 = s7["cw_ok"].all(axis=1)
+    assert np.array_equal(ok7, s7["frame_valid"].astype(bool))
+    assert (out7[torch_idx(ok7)] == info[torch_idx(ok7)]).all()
+    assert (out7[torch_idx(~ok7)] == 0).all() or not s7["cw_ok"][~ok7].all(axis=1).any()
 
 
 def test_channel_statistics():
@@ -210,8 +239,8 @@ def test_channel_statistics():
     import torch
     e = engine("QAM16", "R1_2")
     n, L = 256, e.geo.frame_samples
-    t = torch.arange(L, device="cuda", dtype=torch.float32)
-    x0 = (0.3 * torch.sin(2 * np.pi * 1500.0 * t / 48000.0)).repeat(n, 1).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x0 = 0.3 * torch.randn((n, L), device="cuda", generator=g)  # white input: the two taps add in power
     y = e.channel_(x0.clone(), kind=0, snr_db=10.0, seed=1)
     noise = (y - x0)
     rms = float(x0[0].pow(2).mean().sqrt())
@@ -221,11 +250,11 @@ def test_channel_statistics():
     y = e.channel_(x0.clone(), kind=2, snr_db=200.0, seed=2)
     # frames start with fading state (1,0) and relax with time constant 1/alpha = 15279 samples
     p_out = float(y[:, L // 2:].pow(2).mean()) / float(x0[:, L // 2:].pow(2).mean())
-    assert 0.5 < p_out < 2.0, p_out
+    assert 0.85 < p_out < 1.15, p_out
     # independent frames, deterministic in (seed, frame index)
     y2 = e.channel_(x0.clone(), kind=2, snr_db=200.0, seed=2)
     assert torch.equal(y, y2)
-    y3 = e.channel_(x0[:8].clone(), kind=2, snr_db=200.0, seed=2, first_frame=8)
+    y3 = e.channel_(x0[8:16].clone(), kind=2, snr_db=200.0, seed=2, first_frame=8)
     assert torch.equal(y3, y[8:16])
 
 
