@@ -158,6 +158,10 @@ int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ri
                            ria_decode_status* decode_status_host, float* llr_out_host,
                            ria_frame_status* demod_status_host);
 
+/* Host-buffer decodeFixedFrame (llr_host: n_frames rows of llr_stride floats, first 2592 used). */
+int ria_gpu_decode_frames_host(ria_gpu_handle h, const float* llr_host, int llr_stride, int n_frames, uint32_t flags,
+                               uint8_t* info_out_host, ria_decode_status* status_host);
+
 /* ---- TX synthesis for Monte-Carlo sweeps (v2::encodeFixedFrame frame_v2.cpp:1285-1328 +
  *      OFDMModulator::generateTrainingSymbols/modulate modulator.cpp:534-583, :348-477) ---------- */
 /* info_dev: n_frames * info_bytes_per_frame (already serialized frames, zero padded);

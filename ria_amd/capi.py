@@ -15,7 +15,7 @@ DECODE_NO_CHANNEL_DEINTERLEAVE = 0x100
 EXPORTS = [
     "ria_gpu_abi_version", "ria_gpu_default_config", "ria_gpu_create", "ria_gpu_destroy", "ria_gpu_last_error",
     "ria_gpu_get_geometry", "ria_gpu_demod_batch", "ria_gpu_decode_batch", "ria_gpu_ldpc_decode_batch",
-    "ria_gpu_rx_batch", "ria_gpu_rx_frames_host", "ria_gpu_tx_batch", "ria_gpu_make_frames",
+    "ria_gpu_rx_batch", "ria_gpu_rx_frames_host", "ria_gpu_decode_frames_host", "ria_gpu_tx_batch", "ria_gpu_make_frames",
     "ria_gpu_channel_batch", "ria_gpu_debug_math",
 ]
 
@@ -83,6 +83,7 @@ def load(build_if_needed=True):
     L.ria_gpu_ldpc_decode_batch.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.ria_gpu_rx_batch.argtypes = [vp, vp, vp, vp, i32, u32, vp, vp, vp, vp, vp]
     L.ria_gpu_rx_frames_host.argtypes = [vp, vp, vp, i32, u32, vp, vp, vp, vp]
+    L.ria_gpu_decode_frames_host.argtypes = [vp, vp, i32, i32, u32, vp, vp]
     L.ria_gpu_tx_batch.argtypes = [vp, vp, i32, f32, vp, vp]
     L.ria_gpu_make_frames.argtypes = [vp, u64, i32, i32, vp, vp]
     L.ria_gpu_channel_batch.argtypes = [vp, i32, f32, u64, u64, vp, i32, vp]

@@ -439,6 +439,30 @@ int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ri
     return rc;
 }
 
+int ria_gpu_decode_frames_host(ria_gpu_handle h, const float* llr_host, int llr_stride, int n_frames, uint32_t flags,
+                               uint8_t* info_out_host, ria_decode_status* status_host) {
+    if (!h || !llr_host || !info_out_host || !status_host || n_frames <= 0 || llr_stride < kFrameBits)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_decode_frames_host: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    float* d_llr = nullptr; uint8_t* d_info = nullptr; ria_decode_status* d_ds = nullptr;
+    size_t nl = static_cast<size_t>(n_frames) * llr_stride, ni = static_cast<size_t>(n_frames) * h->geo.info_bytes_per_frame;
+    auto cleanup = [&]() { for (void* p_ : {(void*)d_llr, (void*)d_info, (void*)d_ds}) (void)hipFree(p_); };
+#define H_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_llr), nl * sizeof(float)));
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_info), ni));
+    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_ds), n_frames * sizeof(ria_decode_status)));
+    H_TRY(hipMemcpy(d_llr, llr_host, nl * sizeof(float), hipMemcpyHostToDevice));
+    int rc = ria_gpu_decode_batch(h, d_llr, llr_stride, n_frames, flags, d_info, d_ds, nullptr);
+    if (rc == RIA_OK) {
+        H_TRY(hipDeviceSynchronize());
+        H_TRY(hipMemcpy(info_out_host, d_info, ni, hipMemcpyDeviceToHost));
+        H_TRY(hipMemcpy(status_host, d_ds, n_frames * sizeof(ria_decode_status), hipMemcpyDeviceToHost));
+    }
+#undef H_TRY
+    cleanup();
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------ TX / channel
 int ria_gpu_make_frames(ria_gpu_handle h, uint64_t seed, int first_seq, int n_frames, uint8_t* info_out_dev,
                         void* stream) {

@@ -1,0 +1,40 @@
+// C++ host-side use of the drop-in, written like tools/test_waveform_simple.cpp drives the reference:
+// configure -> reset -> setAbsoluteTrainingPosition -> setFrequencyOffset -> process -> getSoftBits
+// -> decodeFixedFrame (streaming_decoder.cpp:723,896,1347-1363,2821).
+// usage: host_adaptor_test <mod> <rate> <frame.f32> <cfo_hz> <abs_pos> <out_prefix>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../ria_amd/host/gpu_waveform.hpp"
+using namespace ria_host;
+int main(int argc, char** argv) {
+    if (argc < 7) return 2;
+    auto mod = static_cast<Modulation>(atoi(argv[1]));
+    auto rate = static_cast<CodeRate>(atoi(argv[2]));
+    FILE* f = fopen(argv[3], "rb");
+    if (!f) return 3;
+    std::vector<float> x(1 << 20);
+    x.resize(fread(x.data(), 4, x.size(), f));
+    fclose(f);
+    GpuOfdmChirpWaveform rx(mod, rate);
+    GpuHandle dec(mod, rate);
+    rx.reset();
+    rx.setAbsoluteTrainingPosition(static_cast<size_t>(atoll(argv[5])));
+    rx.setFrequencyOffset(static_cast<float>(atof(argv[4])));
+    bool ready = rx.process(SampleSpan{x.data(), x.size()});
+    float snr = rx.estimatedSNR(), cfo = rx.estimatedCFO(), fi = rx.getFadingIndex();
+    std::vector<float> soft = rx.getSoftBits();
+    CodewordStatus st = decodeFixedFrame(rx, dec, soft, true);
+    std::string p = argv[6];
+    FILE* o = fopen((p + ".llr").c_str(), "wb"); fwrite(soft.data(), 4, soft.size(), o); fclose(o);
+    o = fopen((p + ".txt").c_str(), "w");
+    fprintf(o, "%d %zu %.9g %.9g %.9g\n", ready ? 1 : 0, soft.size(), snr, cfo, fi);
+    for (int cw = 0; cw < 4; ++cw) {
+        fprintf(o, "%d %d", st.decoded[cw] ? 1 : 0, st.iterations[cw]);
+        for (uint8_t b : st.data[cw]) fprintf(o, " %u", b);
+        fprintf(o, "\n");
+    }
+    fclose(o);
+    printf("ready=%d soft=%zu decoded=%d%d%d%d\n", ready, soft.size(), (int)st.decoded[0], (int)st.decoded[1], (int)st.decoded[2], (int)st.decoded[3]);
+    return 0;
+}
