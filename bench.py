@@ -180,7 +180,7 @@ def main():
         t_demod += ev[0].elapsed_time(ev[1]) / reps
         t_decode += ev[2].elapsed_time(ev[3]) / reps
     if t_decode >= t_demod:
-        dom, dur_ms, algo = "decode_frames_kernel", t_decode, ALGO_BYTES_DECODE * B
+        dom, dur_ms, algo = "decode kernels (fast_primary+cascade+finalize+validate)", t_decode, ALGO_BYTES_DECODE * B
     else:
         dom, dur_ms, algo = "demod_frames_kernel", t_demod, ALGO_BYTES_DEMOD * B
     achieved = algo / (dur_ms * 1e-3) / 1e9
@@ -212,7 +212,7 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": None,
-                "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_frames_kernel": round(t_decode, 3)},
+                "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

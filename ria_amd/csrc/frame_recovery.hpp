@@ -146,34 +146,51 @@ struct FrameRecovery {
         else insertion(v.data(), v.data() + n);
     }
 
-    // cw: the four decoded codeword payloads (modified in place when recovered).
-    // cwllr: [4][648] decoder-order LLRs.  redec_ok/redec: results of re-decoding each codeword with
-    // factors {0.75, 0.625, 0.5, 0.875} (attempt-major: [attempt][cw]).
-    // Returns true if the frame was recovered (cw now verifies), false -> all codewords are failures.
-    bool recover(uint8_t cw[4][68], const float* cwllr, const uint8_t redec_ok[4][4], const uint8_t redec[4][4][68]) const {
+    // Stage 1 (frame_v2.cpp:1579-1834): CRC-guided bit-flip searches.  cw: the four decoded codeword
+    // payloads (modified in place when recovered); cwllr: [4][648] decoder-order LLRs.
+    bool recover_search(uint8_t cw[4][68], const float* cwllr) const {
         uint8_t fd[4 * 68], trial[4 * 68];
         int flen = reassemble(cw, fd);
         bool recovered = false;
-        auto hdr_ok = [&]() {
-            return cw[0][0] == 0x55 && cw[0][1] == 0x4C && T.crc(cw[0], 15) == static_cast<uint16_t>((cw[0][15] << 8) | cw[0][16]);
-        };
         if (flen == 0) {  // case 1: header CRC error in CW0
+            // hdr_ok() of the reference = magic bytes match && CRC(bytes 0..14) == bytes 15..16.  Both are
+            // linear in the flipped bits, so each candidate is filtered with precomputed per-bit deltas
+            // (same loop order, same first hit as the reference's brute-force recomputation).
+            const int tb = bpc * 8;
+            uint16_t hsyn = static_cast<uint16_t>(T.crc(cw[0], 15) ^ ((cw[0][15] << 8) | cw[0][16]));
+            uint16_t msyn = static_cast<uint16_t>(((cw[0][0] << 8) | cw[0][1]) ^ 0x554C);
+            std::vector<uint16_t> dh(tb, 0), dm(tb, 0);
+            for (int b = 0; b < tb; ++b) {
+                int by = b / 8, bit = b % 8;
+                if (by < 15) dh[b] = T.bit[(14 - by) * 8 + bit];
+                else if (by == 15) dh[b] = static_cast<uint16_t>(1u << (8 + bit));
+                else if (by == 16) dh[b] = static_cast<uint16_t>(1u << bit);
+                if (by == 0) dm[b] = static_cast<uint16_t>(1u << (8 + bit));
+                else if (by == 1) dm[b] = static_cast<uint16_t>(1u << bit);
+            }
             for (int by = 0; by < bpc && !recovered; ++by)
                 for (int bit = 0; bit < 8 && !recovered; ++bit) {
+                    int b = by * 8 + bit;
+                    if ((hsyn ^ dh[b]) != 0 || (msyn ^ dm[b]) != 0) continue;
                     cw[0][by] ^= static_cast<uint8_t>(1 << bit);
-                    if (hdr_ok()) { int tl = reassemble(cw, trial); if (verify(trial, tl)) recovered = true; }
+                    int tl = reassemble(cw, trial);
+                    if (verify(trial, tl)) recovered = true;
                     if (!recovered) cw[0][by] ^= static_cast<uint8_t>(1 << bit);
                 }
             if (!recovered) {
-                int tb = bpc * 8;
                 for (int b1 = 0; b1 < tb && !recovered; ++b1) {
-                    cw[0][b1 / 8] ^= static_cast<uint8_t>(1 << (b1 % 8));
+                    uint16_t h1 = hsyn ^ dh[b1], m1 = msyn ^ dm[b1];
                     for (int b2 = b1 + 1; b2 < tb && !recovered; ++b2) {
+                        if ((h1 ^ dh[b2]) != 0 || (m1 ^ dm[b2]) != 0) continue;
+                        cw[0][b1 / 8] ^= static_cast<uint8_t>(1 << (b1 % 8));
                         cw[0][b2 / 8] ^= static_cast<uint8_t>(1 << (b2 % 8));
-                        if (hdr_ok()) { int tl = reassemble(cw, trial); if (verify(trial, tl)) recovered = true; }
-                        if (!recovered) cw[0][b2 / 8] ^= static_cast<uint8_t>(1 << (b2 % 8));
+                        int tl = reassemble(cw, trial);
+                        if (verify(trial, tl)) recovered = true;
+                        if (!recovered) {
+                            cw[0][b2 / 8] ^= static_cast<uint8_t>(1 << (b2 % 8));
+                            cw[0][b1 / 8] ^= static_cast<uint8_t>(1 << (b1 % 8));
+                        }
                     }
-                    if (!recovered) cw[0][b1 / 8] ^= static_cast<uint8_t>(1 << (b1 % 8));
                 }
             }
         } else {  // case 2: frame CRC error
@@ -194,58 +211,64 @@ struct FrameRecovery {
                                 int fb = (bit >= 8) ? expected - 2 : expected - 1, c = fb / bpc;
                                 if (c < 4) { cw[c][fb % bpc] ^= static_cast<uint8_t>(1 << (bit % 8)); recovered = true; }
                             }
-                    std::vector<Suspect> sus;
-                    for (int c = 0; c < 4; ++c)
-                        for (int i = 0; i < bpc * 8 && i < 648; ++i) {
-                            int fbit = c * bpc * 8 + i;
-                            if (fbit / 8 >= data_bytes) continue;
-                            float l = cwllr[c * 648 + i];
-                            int chb = l < 0, db = (cw[c][i / 8] >> (i % 8)) & 1;
-                            if (chb != db) sus.push_back({fbit, std::fabs(l)});
-                        }
-                    sort_suspects(sus);
-                    int ns = std::min<int>(30, static_cast<int>(sus.size()));
-                    uint16_t sd[30];
-                    for (int i = 0; i < ns; ++i) sd[i] = delta(sus[i].frame_bit);
-                    auto try_set = [&](std::initializer_list<int> idx) {
-                        for (int i : idx) fix(sus[i].frame_bit);
-                        int tl = reassemble(cw, trial);
-                        if (verify(trial, tl)) { recovered = true; return; }
-                        for (int i : idx) fix(sus[i].frame_bit);
-                    };
-                    if (!recovered)
+                    if (!recovered) {
+                        std::vector<Suspect> sus;
+                        for (int c = 0; c < 4; ++c)
+                            for (int i = 0; i < bpc * 8 && i < 648; ++i) {
+                                int fbit = c * bpc * 8 + i;
+                                if (fbit / 8 >= data_bytes) continue;
+                                float l = cwllr[c * 648 + i];
+                                int chb = l < 0, db = (cw[c][i / 8] >> (i % 8)) & 1;
+                                if (chb != db) sus.push_back({fbit, std::fabs(l)});
+                            }
+                        sort_suspects(sus);
+                        int ns = std::min<int>(30, static_cast<int>(sus.size()));
+                        uint16_t sd[30];
+                        for (int i = 0; i < ns; ++i) sd[i] = delta(sus[i].frame_bit);
+                        auto try_set = [&](std::initializer_list<int> idx) {
+                            for (int i : idx) fix(sus[i].frame_bit);
+                            int tl = reassemble(cw, trial);
+                            if (verify(trial, tl)) { recovered = true; return; }
+                            for (int i : idx) fix(sus[i].frame_bit);
+                        };
                         for (int a = 0; a < ns && !recovered; ++a)
                             for (int b = a + 1; b < ns && !recovered; ++b)
                                 if (static_cast<uint16_t>(sd[a] ^ sd[b]) == syn) try_set({a, b});
-                    if (!recovered)
-                        for (int a = 0; a < ns && !recovered; ++a)
-                            for (int b = a + 1; b < ns && !recovered; ++b)
-                                for (int c = b + 1; c < ns && !recovered; ++c)
-                                    if (static_cast<uint16_t>(sd[a] ^ sd[b] ^ sd[c]) == syn) try_set({a, b, c});
-                    if (!recovered) {
-                        int n4 = std::min(ns, 15);
-                        for (int a = 0; a < n4 && !recovered; ++a)
-                            for (int b = a + 1; b < n4 && !recovered; ++b)
-                                for (int c = b + 1; c < n4 && !recovered; ++c)
-                                    for (int d = c + 1; d < n4 && !recovered; ++d)
-                                        if (static_cast<uint16_t>(sd[a] ^ sd[b] ^ sd[c] ^ sd[d]) == syn) try_set({a, b, c, d});
+                        if (!recovered)
+                            for (int a = 0; a < ns && !recovered; ++a)
+                                for (int b = a + 1; b < ns && !recovered; ++b)
+                                    for (int c = b + 1; c < ns && !recovered; ++c)
+                                        if (static_cast<uint16_t>(sd[a] ^ sd[b] ^ sd[c]) == syn) try_set({a, b, c});
+                        if (!recovered) {
+                            int n4 = std::min(ns, 15);
+                            for (int a = 0; a < n4 && !recovered; ++a)
+                                for (int b = a + 1; b < n4 && !recovered; ++b)
+                                    for (int c = b + 1; c < n4 && !recovered; ++c)
+                                        for (int d = c + 1; d < n4 && !recovered; ++d)
+                                            if (static_cast<uint16_t>(sd[a] ^ sd[b] ^ sd[c] ^ sd[d]) == syn) try_set({a, b, c, d});
+                        }
                     }
                 }
             }
         }
-        if (!recovered) {  // fallback: re-decode with other min-sum factors (frame_v2.cpp:1836-1866)
-            for (int at = 0; at < 4 && !recovered; ++at)
-                for (int c = 0; c < 4 && !recovered; ++c) {
-                    if (!redec_ok[at][c] || std::memcmp(redec[at][c], cw[c], bpc) == 0) continue;
-                    uint8_t orig[68];
-                    std::memcpy(orig, cw[c], bpc);
-                    std::memcpy(cw[c], redec[at][c], bpc);
-                    int tl = reassemble(cw, trial);
-                    if (verify(trial, tl)) recovered = true;
-                    else std::memcpy(cw[c], orig, bpc);
-                }
-        }
         return recovered;
+    }
+
+    // Stage 2 (frame_v2.cpp:1836-1866): re-decode with factors {0.75, 0.625, 0.5, 0.875}; the decodes
+    // were run on the GPU beforehand (attempt-major [attempt][cw]).
+    bool recover_fallback(uint8_t cw[4][68], const uint8_t redec_ok[4][4], const uint8_t redec[4][4][68]) const {
+        uint8_t trial[4 * 68];
+        for (int at = 0; at < 4; ++at)
+            for (int c = 0; c < 4; ++c) {
+                if (!redec_ok[at][c] || std::memcmp(redec[at][c], cw[c], bpc) == 0) continue;
+                uint8_t orig[68];
+                std::memcpy(orig, cw[c], bpc);
+                std::memcpy(cw[c], redec[at][c], bpc);
+                int tl = reassemble(cw, trial);
+                if (verify(trial, tl)) return true;
+                std::memcpy(cw[c], orig, bpc);
+            }
+        return false;
     }
 };
 

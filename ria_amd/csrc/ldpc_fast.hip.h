@@ -1,0 +1,493 @@
+// ria_amd/csrc/ldpc_fast.hip.h — register-resident flooding min-sum LDPC(648,k) decoder, v2.
+//
+// Same arithmetic as ldpc_kernels.hip.h (bit-exact LDPCDecoder::decodeBP, ldpc_decoder.cpp:154-260);
+// what changes is where things live and how work is scheduled:
+//   * one wavefront per codeword, NO index loads in the iteration loop: each lane owns rows
+//     i = lane + 64r and information columns j = lane + 64r; their degrees and message-slot addresses
+//     sit in VGPRs (packed u16), loaded once per decode;
+//   * the identity (parity) column k+i has a single edge, to row i, owned by the SAME lane: its
+//     message never touches LDS and its variable update is fused into the check pass;
+//   * the syndrome of iteration t is evaluated inside the check pass of iteration t+1 from per-edge
+//     hard-bit bytes the variable pass leaves next to the messages (no adjacency walk);
+//   * LDS per wave: [6][m] floats + [6][m] bytes (9.7 KB at R1/2), so >= 12 waves per CU;
+//   * the retry cascade (frame_v2.cpp:1415-1546) is a second, persistent kernel over a device-side
+//     work list of (codeword, attempt) units, so one hopeless codeword no longer pins a whole
+//     workgroup for 39 x 80 iterations while its three sibling waves idle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ria_gpu.h"
+#include "devmath.h"
+#include "ldpc_kernels.hip.h"
+
+namespace ria {
+
+constexpr int kInfoSlots = 6;  // information edges per check (max_check_degree, ldpc_decoder.cpp:87)
+
+// Compile-time shape of a code: RR row rounds (ceil(m/64)), IR information-column rounds (ceil(k/64)),
+// DV max information-column degree.
+template <int RR_, int IR_, int DV_>
+struct CodeShape { static constexpr int RR = RR_, IR = IR_, DV = DV_; };
+using ShapeR12 = CodeShape<6, 6, 6>;    // R1/2 and R1/3: m = 324, k = 324, dv <= 6
+using ShapeR14 = CodeShape<8, 3, 13>;   // m = 486, k = 162
+using ShapeR23 = CodeShape<4, 7, 3>;    // m = 216, k = 432
+using ShapeR34 = CodeShape<3, 8, 3>;    // m = 162, k = 486
+using ShapeR56 = CodeShape<2, 9, 3>;    // m = 108, k = 540
+
+struct FastCode {
+    int k, m, max_iter, bytes_per_cw;
+    const uint8_t* row_deg;    // [m]  total degree incl. the identity edge
+    const uint8_t* col_deg;    // [n]
+    const uint16_t* col_slot;  // [max_col_deg][n] slot addresses s*m + i, ascending check order
+    int n;
+};
+
+__host__ __device__ inline int fast_msg_words(int m) { int w = kInfoSlots * m; return w > 1296 ? w : 1296; }
+__host__ __device__ inline int fast_wave_lds_bytes(int m) { return fast_msg_words(m) * 4 + ((kInfoSlots * m + 15) & ~15) + 16; }
+
+template <class S>
+struct FastState {
+    // tables (loaded once)
+    uint32_t rdeg;                 // 4 bits per row round
+    uint32_t cdeg[(S::IR + 7) / 8];  // 4 bits per information column round
+    uint32_t slot[(S::IR * S::DV + 1) / 2];  // packed u16 slot addresses [r][d]
+    // decoder input of the current attempt
+    float li[S::IR];               // information-column LLRs
+    float lp[S::RR];               // identity-column LLRs
+    // running state
+    float pv[S::RR];               // v2c of the identity edges
+    uint32_t phard;                // hard bits of the identity columns (bit r)
+    uint32_t ihard;                // hard bits of the information columns (bit r)
+};
+
+template <class S>
+__device__ __forceinline__ int get_slot(const FastState<S>& st, int r, int d) {
+    uint32_t w = st.slot[(r * S::DV + d) >> 1];
+    return ((r * S::DV + d) & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+template <class S>
+__device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, int lane) {
+    st.rdeg = 0;
+#pragma unroll
+    for (int r = 0; r < S::RR; ++r) {
+        int i = lane + 64 * r;
+        uint32_t d = (i < c.m) ? c.row_deg[i] : 0u;
+        st.rdeg |= d << (4 * r);
+    }
+#pragma unroll
+    for (int w = 0; w < (S::IR + 7) / 8; ++w) st.cdeg[w] = 0;
+#pragma unroll
+    for (int w = 0; w < (S::IR * S::DV + 1) / 2; ++w) st.slot[w] = 0;
+#pragma unroll
+    for (int r = 0; r < S::IR; ++r) {
+        int j = lane + 64 * r;
+        uint32_t d = (j < c.k) ? c.col_deg[j] : 0u;
+        st.cdeg[r >> 3] |= d << (4 * (r & 7));
+#pragma unroll
+        for (int e = 0; e < S::DV; ++e) {
+            uint32_t a = (e < static_cast<int>(d)) ? c.col_slot[e * c.n + j] : 0u;
+            st.slot[(r * S::DV + e) >> 1] |= a << (((r * S::DV + e) & 1) * 16);
+        }
+    }
+}
+
+// Runs the decoder on the LLRs in st.li / st.lp.  Returns LDPCDecoder::lastIterations(); *ok = converged.
+// On return st.ihard holds the information hard bits of the accepted (or last) iteration.
+template <class S>
+__device__ inline int fast_decode(FastState<S>& st, const FastCode& c, float* __restrict__ msg, uint8_t* __restrict__ hb,
+                                  float factor, int max_iter, int lane, bool* ok) {
+    const int m = c.m;
+    // v2c := channel LLR on every edge
+#pragma unroll
+    for (int r = 0; r < S::IR; ++r) {
+        int deg = (st.cdeg[r >> 3] >> (4 * (r & 7))) & 15;
+#pragma unroll
+        for (int d = 0; d < S::DV; ++d)
+            if (d < deg) msg[get_slot(st, r, d)] = st.li[r];
+    }
+#pragma unroll
+    for (int r = 0; r < S::RR; ++r) st.pv[r] = st.lp[r];
+    st.phard = 0; st.ihard = 0;
+    wave_sync();
+    int it = 0;
+    bool success = false;
+    for (;; ++it) {
+        const bool last_check_only = (it == max_iter);  // trailing pass: syndrome of the final iteration
+        int syn = 0;
+#pragma unroll
+        for (int r = 0; r < S::RR; ++r) {
+            const int i = lane + 64 * r;
+            const int deg = (st.rdeg >> (4 * r)) & 15;  // 0 for rows beyond m
+            if (deg > 0) {
+                float v[kInfoSlots + 1];
+                float min1 = 3.402823466e+38f, min2 = 3.402823466e+38f;
+                int arg = -1, neg = 0, par = (st.phard >> r) & 1;
+#pragma unroll
+                for (int s = 0; s < kInfoSlots; ++s) {
+                    if (s < deg - 1) {
+                        float x = msg[s * m + i];
+                        par ^= hb[s * m + i];
+                        v[s] = x;
+                        neg ^= (x < 0.0f) ? 1 : 0;
+                        float a = fabs_(x);
+                        if (a < min1) { min2 = min1; min1 = a; arg = s; }
+                        else if (a < min2) { min2 = a; }
+                    }
+                }
+                syn |= par;
+                if (!last_check_only) {
+                    {   // identity edge (always the last one of the row: reference edge order)
+                        float x = st.pv[r];
+                        v[kInfoSlots] = x;
+                        neg ^= (x < 0.0f) ? 1 : 0;
+                        float a = fabs_(x);
+                        if (a < min1) { min2 = min1; min1 = a; arg = kInfoSlots; }
+                        else if (a < min2) { min2 = a; }
+                    }
+#pragma unroll
+                    for (int s = 0; s < kInfoSlots; ++s) {
+                        if (s < deg - 1) {
+                            int sg = neg ^ ((v[s] < 0.0f) ? 1 : 0);
+                            float mn = (s == arg) ? min2 : min1;
+                            msg[s * m + i] = (sg ? -mn : mn) * factor;
+                        }
+                    }
+                    {   // identity column: degree 1, so total = llr + c2v and v2c = clamp(total - c2v)
+                        int sg = neg ^ ((v[kInfoSlots] < 0.0f) ? 1 : 0);
+                        float mn = (arg == kInfoSlots) ? min2 : min1;
+                        float c2v = (sg ? -mn : mn) * factor;
+                        float tot = st.lp[r] + c2v;
+                        float x = tot - c2v;
+                        x = (x < 50.0f) ? x : 50.0f;
+                        x = (-50.0f < x) ? x : -50.0f;
+                        st.pv[r] = x;
+                        st.phard = (st.phard & ~(1u << r)) | ((tot < 0.0f) ? (1u << r) : 0u);
+                    }
+                }
+            }
+        }
+        if (it > 0 && __ballot(syn != 0) == 0ull) { success = true; --it; break; }
+        if (last_check_only) break;
+        wave_sync();
+        // information columns
+#pragma unroll
+        for (int r = 0; r < S::IR; ++r) {
+            int deg = (st.cdeg[r >> 3] >> (4 * (r & 7))) & 15;
+            float tot = st.li[r];
+            float cv[S::DV];
+#pragma unroll
+            for (int d = 0; d < S::DV; ++d)
+                if (d < deg) { cv[d] = msg[get_slot(st, r, d)]; tot += cv[d]; }
+            int hbit = (tot < 0.0f) ? 1 : 0;
+#pragma unroll
+            for (int d = 0; d < S::DV; ++d)
+                if (d < deg) {
+                    int a = get_slot(st, r, d);
+                    float x = tot - cv[d];
+                    x = (x < 50.0f) ? x : 50.0f;
+                    x = (-50.0f < x) ? x : -50.0f;
+                    msg[a] = x;
+                    hb[a] = static_cast<uint8_t>(hbit);
+                }
+            st.ihard = (st.ihard & ~(1u << r)) | (static_cast<uint32_t>(hbit) << r);
+        }
+        wave_sync();
+    }
+    *ok = success;
+    return success ? it : max_iter;
+}
+
+// information hard bits -> bytes, MSB first (decodeBP's packing); scratch: >= 8*IR bytes of LDS
+template <class S>
+__device__ inline void fast_pack(const FastState<S>& st, const FastCode& c, uint8_t* scratch, uint8_t* out, int nbytes,
+                                 int lane) {
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(scratch);
+#pragma unroll
+    for (int r = 0; r < S::IR; ++r) {
+        bool bit = ((st.ihard >> r) & 1u) && (lane + 64 * r < c.k);
+        unsigned long long mk = __ballot(bit);
+        if (lane == 0) masks[r] = mk;
+    }
+    wave_sync();
+    for (int b = lane; b < nbytes; b += 64) out[b] = static_cast<uint8_t>(__brev(static_cast<unsigned>(scratch[b])) >> 24);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------ args
+struct DecodeCtl {          // zeroed by hipMemsetAsync before every decode call
+    unsigned int n_entries; // codewords that need the cascade
+    unsigned int next_unit; // cascade work queue head
+    unsigned int pad[2];
+};
+
+struct FastDecodeArgs {
+    FastCode c;
+    const uint16_t* gather;
+    const float* llr;
+    int llr_stride;
+    int n_frames;
+    uint32_t flags;
+    uint8_t* info_out;
+    ria_decode_status* status;
+    const uint16_t* crc_bit;
+    const uint16_t* crc_init;
+    DecodeCtl* ctl;
+    unsigned int* entries;   // [4*n_frames]  frame*4 + cw
+    unsigned int* best;      // [4*n_frames]  first successful cascade attempt (0..33) or 0xFFFFFFFF
+};
+
+template <class S>
+__device__ inline void fast_gather_llr(FastState<S>& st, const FastCode& c, const float* fl, const uint16_t* gather,
+                                       int cw, int lane) {
+#pragma unroll
+    for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? fl[gather[cw * 648 + j]] : 0.0f; }
+#pragma unroll
+    for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? fl[gather[cw * 648 + c.k + i]] : 0.0f; }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel D1
+// primary decode + phase 0 + decoder-factor chain; 4 waves = the 4 codewords of a frame
+template <class S>
+__global__ __launch_bounds__(256) void fast_primary_kernel(FastDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FastCode& c = A.c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frame = blockIdx.x;
+    const int wb = fast_wave_lds_bytes(c.m);
+    float* msg = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * wb);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
+    volatile int* res = reinterpret_cast<volatile int*>(smem + 4 * static_cast<size_t>(wb));  // [4][2]
+    FastState<S> st;
+    fast_load_tables(st, c, lane);
+    fast_gather_llr(st, c, A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, wave, lane);
+    bool ok = false, p_ok = false, p0_ok = false;
+    int iters = 0, attempts = 0;
+    auto primary_and_phase0 = [&](float f_before) {
+        attempts = 1;
+        iters = fast_decode(st, c, msg, hb, f_before, c.max_iter, lane, &ok);
+        p_ok = ok; p0_ok = false;
+        if (!ok && (A.flags & RIA_DECODE_PHASE0)) {
+            const float f0[4] = {0.875f, 0.75f, 0.625f, 0.5f};
+            for (int t = 0; t < 4 && !ok; ++t) {
+                bool k2; attempts++;
+                int it = fast_decode(st, c, msg, hb, f0[t], c.max_iter, lane, &k2);
+                if (k2) { ok = true; iters = it; }
+            }
+            p0_ok = ok;
+        }
+        if (lane == 0) { res[wave * 2 + 0] = p_ok; res[wave * 2 + 1] = p0_ok; }
+    };
+    primary_and_phase0(0.9375f);
+    __syncthreads();
+    float f = 0.9375f;   // decoder-factor chain across the frame's codewords (see ldpc_kernels.hip.h)
+    for (int cw = 0; cw < 4; ++cw) {
+        if (cw > 0) {
+            if (wave == cw && f != 0.9375f) primary_and_phase0(f);
+            __syncthreads();
+        }
+        bool pk = res[cw * 2 + 0] != 0, p0k = res[cw * 2 + 1] != 0;
+        if (!pk) {
+            if (A.flags & RIA_DECODE_PHASE0) f = 0.9375f;
+            if (!p0k && (A.flags & RIA_DECODE_PERTURB)) f = 0.875f;
+        }
+    }
+    const int bpc = c.bytes_per_cw;
+    uint8_t* out = A.info_out + (static_cast<size_t>(frame) * 4 + wave) * bpc;
+    if (ok) fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), out, bpc, lane);
+    else for (int b = lane; b < bpc; b += 64) out[b] = 0;
+    if (lane == 0) {
+        ria_decode_status* s = A.status + frame;
+        s->cw_ok[wave] = ok ? 1 : 0;
+        s->iterations[wave] = static_cast<uint16_t>(iters);
+        s->attempts[wave] = static_cast<uint8_t>(attempts);
+        if (!ok && (A.flags & RIA_DECODE_PERTURB)) {
+            unsigned int e = atomicAdd(&A.ctl->n_entries, 1u);
+            A.entries[e] = static_cast<unsigned>(frame) * 4u + static_cast<unsigned>(wave);
+            A.best[e] = 0xFFFFFFFFu;
+        }
+    }
+}
+
+// perturbed decoder input of cascade attempt a (frame_v2.cpp:1415-1546) into st.li/st.lp
+template <class S>
+__device__ inline float fast_perturb(FastState<S>& st, const FastCode& c, const float* base_i, const float* base_p,
+                                     uint32_t* mt, float* normal, int a, uint32_t h, int lane) {
+    uint32_t seed; float sigma, factor; int kind;
+    retry_transform_params(a, h, &seed, &sigma, &factor, &kind);
+    normal648_wave(mt, normal, seed, lane);
+    auto tf = [&](float v, float nz) {
+        if (kind == 1) { v = (v < 10.0f) ? v : 10.0f; v = (-10.0f < v) ? v : -10.0f; }
+        else if (kind == 2) v = v * 0.5f;
+        else if (kind == 3) { v = (v < 6.0f) ? v : 6.0f; v = (-6.0f < v) ? v : -6.0f; }
+        else if (kind == 4) v = (v >= 0.0f) ? 1.0f : -1.0f;
+        else if (kind == 5) v = v * 0.25f;
+        return v + (nz * sigma + 0.0f);
+    };
+#pragma unroll
+    for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? tf(base_i[r], normal[j]) : 0.0f; }
+#pragma unroll
+    for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? tf(base_p[r], normal[c.k + i]) : 0.0f; }
+    wave_sync();
+    return factor;
+}
+
+template <class S>
+__device__ inline uint32_t fast_hash16(const FastState<S>& st) {  // frame_v2.cpp:1391-1396
+    uint32_t h = 0;
+    for (int j = 0; j < 16; ++j) {
+        uint32_t u = f2u(__shfl(st.li[0], j));
+        h ^= u + 0x9e3779b9u + (h << 6) + (h >> 2);
+    }
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel D2
+// persistent single-wave workgroups; unit u = attempt-major (a = u / n_entries, e = u % n_entries)
+template <class S>
+__global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FastCode& c = A.c;
+    const int lane = threadIdx.x;
+    float* msg = reinterpret_cast<float*>(smem);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
+    const unsigned int n_entries = A.ctl->n_entries;
+    const unsigned int total = n_entries * 34u;
+    if (total == 0) return;
+    FastState<S> st;
+    fast_load_tables(st, c, lane);
+    for (;;) {
+        unsigned int u = 0;
+        if (lane == 0) u = atomicAdd(&A.ctl->next_unit, 1u);
+        u = __shfl(u, 0);
+        if (u >= total) break;
+        const unsigned int a = u / n_entries, e = u - a * n_entries;
+        unsigned int b = __hip_atomic_load(&A.best[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __shfl(b, 0);
+        if (b < a) continue;  // an earlier attempt already succeeded: this one can never be chosen
+        const unsigned int fc = A.entries[e];
+        fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
+        float bi[S::IR], bp[S::RR];
+#pragma unroll
+        for (int r = 0; r < S::IR; ++r) bi[r] = st.li[r];
+#pragma unroll
+        for (int r = 0; r < S::RR; ++r) bp[r] = st.lp[r];
+        uint32_t h = fast_hash16(st);
+        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
+        bool ok;
+        (void)fast_decode(st, c, msg, hb, factor, c.max_iter, lane, &ok);
+        if (ok && lane == 0) atomicMin(&A.best[e], a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel D3
+// one wave per cascade entry: re-run the winning attempt (deterministic) and publish its bytes
+template <class S>
+__global__ __launch_bounds__(64) void fast_finalize_kernel(FastDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FastCode& c = A.c;
+    const int lane = threadIdx.x;
+    const unsigned int n_entries = A.ctl->n_entries;
+    float* msg = reinterpret_cast<float*>(smem);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
+    for (unsigned int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const unsigned int fc = A.entries[e], frame = fc >> 2, cw = fc & 3;
+        const unsigned int a = A.best[e];
+        ria_decode_status* s = A.status + frame;
+        if (a >= 34u) {
+            if (lane == 0) s->attempts[cw] = static_cast<uint8_t>(s->attempts[cw] + 34);
+            continue;
+        }
+        FastState<S> st;
+        fast_load_tables(st, c, lane);
+        fast_gather_llr(st, c, A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, cw, lane);
+        float bi[S::IR], bp[S::RR];
+#pragma unroll
+        for (int r = 0; r < S::IR; ++r) bi[r] = st.li[r];
+#pragma unroll
+        for (int r = 0; r < S::RR; ++r) bp[r] = st.lp[r];
+        uint32_t h = fast_hash16(st);
+        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
+        bool ok;
+        int it = fast_decode(st, c, msg, hb, factor, c.max_iter, lane, &ok);
+        fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), A.info_out + (static_cast<size_t>(frame) * 4 + cw) * c.bytes_per_cw,
+                  c.bytes_per_cw, lane);
+        if (lane == 0) {
+            s->cw_ok[cw] = ok ? 1 : 0;  // ok is true by construction
+            s->iterations[cw] = static_cast<uint16_t>(it);
+            s->attempts[cw] = static_cast<uint8_t>(s->attempts[cw] + a + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel D4
+// frame validity: parseHeader + DataFrame::deserialize on the straight concatenation
+// (frame_v2.cpp:1195-1252, :556-600); CW1..3 starting with 0xD5 go to the host restatement.
+__global__ __launch_bounds__(256) void frame_validate_kernel(const uint8_t* __restrict__ info, int bpc, int n_frames,
+                                                             const uint16_t* __restrict__ crc_bit,
+                                                             const uint16_t* __restrict__ crc_init,
+                                                             ria_decode_status* __restrict__ status) {
+    __shared__ uint8_t flat_all[4][4 * 68];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * 4 + wave;
+    if (frame >= n_frames) return;
+    uint8_t* flat = flat_all[wave];
+    ria_decode_status* s = status + frame;
+    const bool all_ok = s->cw_ok[0] && s->cw_ok[1] && s->cw_ok[2] && s->cw_ok[3];
+    int valid = 0, quirk = 0;
+    if (all_ok) {
+        for (int b = lane; b < 4 * bpc; b += 64) flat[b] = info[static_cast<size_t>(frame) * 4 * bpc + b];
+        wave_sync();
+        bool magic = flat[0] == 0x55 && flat[1] == 0x4C;
+        int t = flat[2];
+        bool ctl = (t == 0x10 || t == 0x11 || t == 0x16 || t == 0x17 || t == 0x20 || t == 0x21 || t == 0x15 || t == 0x40);
+        int plen = (flat[13] << 8) | flat[14];
+        int expected = ctl ? 20 : 17 + plen + 2;
+        for (int cw = 1; cw < 4; ++cw) if (cw * bpc < expected && flat[cw * bpc] == 0xD5) quirk = 1;
+        if (magic && !quirk) {
+            if (ctl) {
+                uint32_t crc = crc16_wave(flat, 18, crc_bit, crc_init, lane);
+                valid = crc == static_cast<uint32_t>((flat[18] << 8) | flat[19]);
+            } else {
+                uint32_t hc = crc16_wave(flat, 15, crc_bit, crc_init, lane);
+                if (hc == static_cast<uint32_t>((flat[15] << 8) | flat[16]) && expected <= 4 * bpc) {
+                    uint32_t fc = crc16_wave(flat, expected - 2, crc_bit, crc_init, lane);
+                    valid = fc == static_cast<uint32_t>((flat[expected - 2] << 8) | flat[expected - 1]);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        s->frame_valid = static_cast<uint8_t>(valid);
+        s->needs_recovery = static_cast<uint8_t>(all_ok && !valid);
+        s->reserved[0] = static_cast<uint8_t>(quirk);
+        s->reserved[1] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ raw rows
+template <class S>
+__global__ __launch_bounds__(64) void fast_rows_kernel(FastCode c, const float* __restrict__ llr, int n_cw, int max_iter,
+                                                       float factor, uint8_t* __restrict__ out, uint8_t* __restrict__ ok_out,
+                                                       uint16_t* __restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    float* msg = reinterpret_cast<float*>(smem);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
+    FastState<S> st;
+    fast_load_tables(st, c, lane);
+    const int nb = (c.k + 7) / 8;
+    for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
+        const float* l = llr + static_cast<size_t>(cw) * 648;
+#pragma unroll
+        for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? l[j] : 0.0f; }
+#pragma unroll
+        for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? l[c.k + i] : 0.0f; }
+        bool ok;
+        int it = fast_decode(st, c, msg, hb, factor, max_iter, lane, &ok);
+        fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), out + static_cast<size_t>(cw) * nb, nb, lane);
+        if (lane == 0) { ok_out[cw] = ok ? 1 : 0; iters_out[cw] = static_cast<uint16_t>(it); }
+    }
+}
+
+}  // namespace ria

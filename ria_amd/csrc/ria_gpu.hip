@@ -5,14 +5,18 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ria_gpu.h"
 #include "host_tables.hpp"
 #include "frame_recovery.hpp"
 #include "ldpc_kernels.hip.h"
+#include "ldpc_fast.hip.h"
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
 
@@ -35,6 +39,11 @@ struct ria_gpu {
     // workspace
     float* d_llr_ws = nullptr;            // max_batch * llrs_per_frame (fused path)
     LdpcDev ldpc_dev{};
+    FastCode fast{};
+    DecodeCtl* d_ctl = nullptr;           // cascade work-list control block
+    unsigned int* d_entries = nullptr;    // [4 * ws_frames]
+    unsigned int* d_best = nullptr;       // [4 * ws_frames]
+    int ws_frames = 0;
     Crc16Tables crc;
 };
 
@@ -75,6 +84,51 @@ uint16_t crc16_host(const uint8_t* d, int n, uint16_t init) {  // frame_v2.cpp:1
 
 }  // namespace
 
+// ---- rate -> compiled code shape ------------------------------------------------------------------
+template <class F>
+static void dispatch_shape(int rate, F&& f) {
+    switch (rate) {
+        case RIA_RATE_1_4: f(ShapeR14{}); break;
+        case RIA_RATE_2_3: f(ShapeR23{}); break;
+        case RIA_RATE_3_4: f(ShapeR34{}); break;
+        case RIA_RATE_5_6: f(ShapeR56{}); break;
+        default: f(ShapeR12{}); break;  // R1/2, R1/3 (k = m = 324)
+    }
+}
+static bool shape_fits(int rate, const LdpcCode& c) {
+    bool ok = false;
+    dispatch_shape(rate, [&](auto s) {
+        using S = decltype(s);
+        ok = (c.m + 63) / 64 <= S::RR && (c.k + 63) / 64 <= S::IR && c.max_col_deg <= S::DV && S::RR <= 8;
+        int max_row = 0;
+        for (auto d : c.row_deg) max_row = std::max<int>(max_row, d);
+        ok = ok && max_row <= kInfoSlots + 1;
+    });
+    return ok;
+}
+static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
+    if (n_frames <= h->ws_frames && h->d_ctl) return hipSuccess;
+    if (h->d_entries) (void)hipFree(h->d_entries);
+    if (h->d_best) (void)hipFree(h->d_best);
+    h->d_entries = h->d_best = nullptr;
+    hipError_t e;
+    if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), sizeof(DecodeCtl))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_entries), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_best), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
+    h->ws_frames = n_frames;
+    return hipSuccess;
+}
+static void set_fast_attributes(int rate, int m) {
+    dispatch_shape(rate, [&](auto s) {
+        using S = decltype(s);
+        int wb = fast_wave_lds_bytes(m);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_primary_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * wb + 64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_finalize_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+    });
+}
+
 // ---- CRC-guided false-positive recovery glue (host logic in frame_recovery.hpp) -----------------
 __global__ void gather_rows_kernel(const float* __restrict__ llr, int stride, const int* __restrict__ frame_idx,
                                    const uint16_t* __restrict__ gather, float* __restrict__ rows) {
@@ -92,7 +146,32 @@ __global__ void scatter_results_kernel(const int* __restrict__ frame_idx, const 
     if (threadIdx.x == 0) st_out[dst] = st_c[f];
 }
 
-// Runs after decode_frames_kernel when RIA_DECODE_CRC_RECOVER is set.  Synchronises the stream.
+__global__ void gather_info_kernel(const int* __restrict__ frame_idx, const uint8_t* __restrict__ info, int info_bytes,
+                                   uint8_t* __restrict__ info_c) {
+    int f = blockIdx.x;
+    for (int i = threadIdx.x; i < info_bytes; i += blockDim.x)
+        info_c[static_cast<size_t>(f) * info_bytes + i] = info[static_cast<size_t>(frame_idx[f]) * info_bytes + i];
+}
+__global__ void gather_rows_subset_kernel(const float* __restrict__ rows, const int* __restrict__ sub, float* __restrict__ out) {
+    // sub[b >> 2] = index of a flagged frame inside the compact rows array
+    size_t src = (static_cast<size_t>(sub[blockIdx.x >> 2]) * 4 + (blockIdx.x & 3)) * 648;
+    for (int i = threadIdx.x; i < 648; i += blockDim.x) out[static_cast<size_t>(blockIdx.x) * 648 + i] = rows[src + i];
+}
+
+template <class F>
+static void parallel_for(int n, F&& f) {
+    int nt = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+    if (n < 64 || nt == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&]() { for (;;) { int i0 = next.fetch_add(32); if (i0 >= n) return; for (int i = i0; i < std::min(n, i0 + 32); ++i) f(i); } });
+    for (auto& t : th) t.join();
+}
+
+// Runs after the decode kernels when RIA_DECODE_CRC_RECOVER is set.  Synchronises the stream.
+// Stage 1 (CRC-guided searches) runs on the host threads for every flagged frame; only the frames
+// it cannot repair get the 16 re-decodes of stage 2, batched on the GPU.
 static int run_crc_recovery(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
                             uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s) {
     std::vector<ria_decode_status> st(n_frames);
@@ -104,57 +183,83 @@ static int run_crc_recovery(ria_gpu_handle h, const float* llr_dev, int llr_stri
     const int nf = static_cast<int>(idx.size()), bpc = h->geo.bytes_per_codeword, ib = h->geo.info_bytes_per_frame;
     const int nb = (h->geo.info_bits + 7) / 8;
     int* d_idx = nullptr; float* d_rows = nullptr; uint8_t* d_out = nullptr; uint8_t* d_ok = nullptr; uint16_t* d_it = nullptr;
-    uint8_t* d_info_c = nullptr; ria_decode_status* d_st_c = nullptr;
-    auto cleanup = [&]() { for (void* p_ : {(void*)d_idx, (void*)d_rows, (void*)d_out, (void*)d_ok, (void*)d_it, (void*)d_info_c, (void*)d_st_c}) (void)hipFree(p_); };
+    uint8_t* d_info_c = nullptr; ria_decode_status* d_st_c = nullptr; int* d_sub = nullptr; float* d_rows2 = nullptr;
+    auto cleanup = [&]() { for (void* p_ : {(void*)d_idx, (void*)d_rows, (void*)d_out, (void*)d_ok, (void*)d_it, (void*)d_info_c, (void*)d_st_c, (void*)d_sub, (void*)d_rows2}) (void)hipFree(p_); };
 #define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
     const int ncw = nf * 4;
     R_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), nf * sizeof(int)));
     R_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), static_cast<size_t>(ncw) * 648 * sizeof(float)));
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), static_cast<size_t>(4) * ncw * nb));
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_ok), static_cast<size_t>(4) * ncw));
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_it), static_cast<size_t>(4) * ncw * sizeof(uint16_t)));
     R_TRY(hipMalloc(reinterpret_cast<void**>(&d_info_c), static_cast<size_t>(nf) * ib));
     R_TRY(hipMalloc(reinterpret_cast<void**>(&d_st_c), static_cast<size_t>(nf) * sizeof(ria_decode_status)));
     R_TRY(hipMemcpyAsync(d_idx, idx.data(), nf * sizeof(int), hipMemcpyHostToDevice, s));
     const uint16_t* gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(ncw), dim3(128), 0, s, llr_dev, llr_stride, d_idx, gather, d_rows);
-    static const float rf[4] = {0.75f, 0.625f, 0.5f, 0.875f};  // frame_v2.cpp:1837
-    int lds = 4 * ldpc_wave_lds_bytes(h->ldpc_dev.m);
-    for (int at = 0; at < 4; ++at)
-        hipLaunchKernelGGL(ldpc_decode_rows_kernel, dim3((ncw + 3) / 4), dim3(256), lds, s, h->ldpc_dev, d_rows, ncw,
-                           h->geo.ldpc_max_iterations, rf[at], d_out + static_cast<size_t>(at) * ncw * nb,
-                           d_ok + static_cast<size_t>(at) * ncw, d_it + static_cast<size_t>(at) * ncw);
+    hipLaunchKernelGGL(gather_info_kernel, dim3(nf), dim3(64), 0, s, d_idx, info_out_dev, ib, d_info_c);
     R_TRY(hipGetLastError());
     std::vector<float> rows(static_cast<size_t>(ncw) * 648);
-    std::vector<uint8_t> out(static_cast<size_t>(4) * ncw * nb), ok(static_cast<size_t>(4) * ncw), info_c(static_cast<size_t>(nf) * ib);
+    std::vector<uint8_t> info_c(static_cast<size_t>(nf) * ib);
     std::vector<ria_decode_status> st_c(nf);
     R_TRY(hipMemcpyAsync(rows.data(), d_rows, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    R_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, s));
-    R_TRY(hipMemcpyAsync(ok.data(), d_ok, ok.size(), hipMemcpyDeviceToHost, s));
-    for (int i = 0; i < nf; ++i)
-        R_TRY(hipMemcpyAsync(info_c.data() + static_cast<size_t>(i) * ib, info_out_dev + static_cast<size_t>(idx[i]) * ib, ib,
-                             hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(info_c.data(), d_info_c, info_c.size(), hipMemcpyDeviceToHost, s));
     R_TRY(hipStreamSynchronize(s));
     FrameRecovery rec(h->crc, bpc);
-    for (int i = 0; i < nf; ++i) {
-        uint8_t cw[4][68], rd[4][4][68], rok[4][4];
-        std::memset(cw, 0, sizeof(cw));
+    std::vector<uint8_t> good(nf, 0);
+    auto load_cw = [&](int i, uint8_t cw[4][68]) {
+        std::memset(cw, 0, 4 * 68);
         for (int c = 0; c < 4; ++c) std::memcpy(cw[c], info_c.data() + static_cast<size_t>(i) * ib + c * bpc, bpc);
+    };
+    auto store_cw = [&](int i, uint8_t cw[4][68]) {
+        for (int c = 0; c < 4; ++c) std::memcpy(info_c.data() + static_cast<size_t>(i) * ib + c * bpc, cw[c], bpc);
+    };
+    parallel_for(nf, [&](int i) {
+        uint8_t cw[4][68];
+        load_cw(i, cw);
+        if (rec.recover_search(cw, rows.data() + static_cast<size_t>(i) * 4 * 648)) { good[i] = 1; store_cw(i, cw); }
+    });
+    std::vector<int> sub;
+    for (int i = 0; i < nf; ++i) if (!good[i]) sub.push_back(i);
+    if (!sub.empty()) {
+        const int ns = static_cast<int>(sub.size()), ncw2 = ns * 4;
+        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_sub), ns * sizeof(int)));
+        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows2), static_cast<size_t>(ncw2) * 648 * sizeof(float)));
+        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), static_cast<size_t>(4) * ncw2 * nb));
+        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_ok), static_cast<size_t>(4) * ncw2));
+        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_it), static_cast<size_t>(4) * ncw2 * sizeof(uint16_t)));
+        R_TRY(hipMemcpyAsync(d_sub, sub.data(), ns * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(gather_rows_subset_kernel, dim3(ncw2), dim3(128), 0, s, d_rows, d_sub, d_rows2);
+        static const float rf[4] = {0.75f, 0.625f, 0.5f, 0.875f};  // frame_v2.cpp:1837
         for (int at = 0; at < 4; ++at)
-            for (int c = 0; c < 4; ++c) {
-                size_t r = static_cast<size_t>(at) * ncw + static_cast<size_t>(i) * 4 + c;
-                rok[at][c] = ok[r];
-                std::memcpy(rd[at][c], out.data() + r * nb, bpc);
-            }
-        bool good = rec.recover(cw, rows.data() + static_cast<size_t>(i) * 4 * 648, rok, rd);
+            dispatch_shape(h->cfg.code_rate, [&](auto sh) {
+                using S = decltype(sh);
+                hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(ncw2, 8192)), dim3(64), fast_wave_lds_bytes(h->fast.m), s,
+                                   h->fast, d_rows2, ncw2, h->geo.ldpc_max_iterations, rf[at],
+                                   d_out + static_cast<size_t>(at) * ncw2 * nb, d_ok + static_cast<size_t>(at) * ncw2,
+                                   d_it + static_cast<size_t>(at) * ncw2);
+            });
+        R_TRY(hipGetLastError());
+        std::vector<uint8_t> out(static_cast<size_t>(4) * ncw2 * nb), ok(static_cast<size_t>(4) * ncw2);
+        R_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, s));
+        R_TRY(hipMemcpyAsync(ok.data(), d_ok, ok.size(), hipMemcpyDeviceToHost, s));
+        R_TRY(hipStreamSynchronize(s));
+        parallel_for(ns, [&](int q) {
+            int i = sub[q];
+            uint8_t cw[4][68], rd[4][4][68], rok[4][4];
+            load_cw(i, cw);
+            for (int at = 0; at < 4; ++at)
+                for (int c = 0; c < 4; ++c) {
+                    size_t r = static_cast<size_t>(at) * ncw2 + static_cast<size_t>(q) * 4 + c;
+                    rok[at][c] = ok[r];
+                    std::memcpy(rd[at][c], out.data() + r * nb, bpc);
+                }
+            if (rec.recover_fallback(cw, rok, rd)) { good[i] = 1; store_cw(i, cw); }
+        });
+    }
+    for (int i = 0; i < nf; ++i) {
         ria_decode_status sn = st[idx[i]];
         sn.needs_recovery = 0;
-        sn.frame_valid = good ? 1 : 0;
-        for (int c = 0; c < 4; ++c) {
-            sn.cw_ok[c] = good ? 1 : 0;
-            if (good) std::memcpy(info_c.data() + static_cast<size_t>(i) * ib + c * bpc, cw[c], bpc);
-            else std::memset(info_c.data() + static_cast<size_t>(i) * ib + c * bpc, 0, bpc);
-        }
+        sn.frame_valid = good[i];
+        for (int c = 0; c < 4; ++c) sn.cw_ok[c] = good[i];
+        if (!good[i]) std::memset(info_c.data() + static_cast<size_t>(i) * ib, 0, ib);
         st_c[i] = sn;
     }
     R_TRY(hipMemcpyAsync(d_info_c, info_c.data(), info_c.size(), hipMemcpyHostToDevice, s));
@@ -191,7 +296,8 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
-                    h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws};
+                    h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
+                    h->d_ctl, h->d_entries, h->d_best};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -282,6 +388,11 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     L.col_deg = static_cast<const uint8_t*>(h->d_col_deg);
     L.col_slot = static_cast<const uint16_t*>(h->d_col_slot);
 
+    h->fast.k = L.k; h->fast.m = L.m; h->fast.n = L.n; h->fast.max_iter = L.max_iter; h->fast.bytes_per_cw = L.bytes_per_cw;
+    h->fast.row_deg = L.row_deg; h->fast.col_deg = L.col_deg; h->fast.col_slot = L.col_slot;
+    if (!shape_fits(cfg->code_rate, h->code)) { ria_gpu_destroy(h); return RIA_ERR_UNSUPPORTED; }
+    set_fast_attributes(cfg->code_rate, L.m);
+    CREATE_TRY(ensure_decode_ws(h, h->cfg.max_batch));
     // dynamic LDS above 64 KiB must be opted into per kernel
     int frame_lds = 4 * ldpc_wave_lds_bytes(L.m) + kFrameSharedBytes;
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_frames_kernel),
@@ -308,17 +419,22 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
         return fail(h, RIA_ERR_INVALID, "ria_gpu_ldpc_decode_batch: bad argument");
     if (n_cw == 0) return RIA_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    int lds = 4 * ldpc_wave_lds_bytes(h->ldpc_dev.m);
-    hipLaunchKernelGGL(ldpc_decode_rows_kernel, dim3((n_cw + 3) / 4), dim3(256), lds, static_cast<hipStream_t>(stream),
-                       h->ldpc_dev, llr_dev, n_cw, max_iterations, min_sum_factor, out_dev, ok_dev, iters_dev);
+    dispatch_shape(h->cfg.code_rate, [&](auto sh) {
+        using S = decltype(sh);
+        hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), fast_wave_lds_bytes(h->fast.m),
+                           static_cast<hipStream_t>(stream), h->fast, llr_dev, n_cw, max_iterations, min_sum_factor,
+                           out_dev, ok_dev, iters_dev);
+    });
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }
 
 static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
                          uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s) {
-    FrameDecodeArgs A;
-    A.c = h->ldpc_dev;
+    hipError_t e = ensure_decode_ws(h, n_frames);
+    if (e != hipSuccess) return fail(h, RIA_ERR_HIP, "decode workspace: %s", hipGetErrorString(e));
+    FastDecodeArgs A;
+    A.c = h->fast;
     A.gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
     A.llr = llr_dev;
     A.llr_stride = llr_stride;
@@ -328,8 +444,23 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.status = status_dev;
     A.crc_bit = static_cast<const uint16_t*>(h->d_crc_bit);
     A.crc_init = static_cast<const uint16_t*>(h->d_crc_init);
-    int lds = 4 * ldpc_wave_lds_bytes(h->ldpc_dev.m) + kFrameSharedBytes;
-    hipLaunchKernelGGL(decode_frames_kernel, dim3(n_frames), dim3(256), lds, s, A);
+    A.ctl = h->d_ctl;
+    A.entries = h->d_entries;
+    A.best = h->d_best;
+    if ((e = hipMemsetAsync(h->d_ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
+        return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const int wb = fast_wave_lds_bytes(h->fast.m);
+    dispatch_shape(h->cfg.code_rate, [&](auto sh) {
+        using S = decltype(sh);
+        hipLaunchKernelGGL(fast_primary_kernel<S>, dim3(n_frames), dim3(256), 4 * wb + 64, s, A);
+        if (flags & RIA_DECODE_PERTURB) {
+            // persistent waves over the device-side work list; sized to fill the chip (256 CUs x 12)
+            hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(3072), dim3(64), wb, s, A);
+            hipLaunchKernelGGL(fast_finalize_kernel<S>, dim3(2048), dim3(64), wb, s, A);
+        }
+    });
+    hipLaunchKernelGGL(frame_validate_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, s, info_out_dev,
+                       h->geo.bytes_per_codeword, n_frames, A.crc_bit, A.crc_init, status_dev);
     return RIA_OK;
 }
 
