@@ -219,8 +219,18 @@ __device__ inline void fast_pack(const FastState<S>& st, const FastCode& c, uint
 struct DecodeCtl {          // zeroed by hipMemsetAsync before every decode call
     unsigned int n_entries; // codewords that need the cascade
     unsigned int next_unit; // cascade work queue head
-    unsigned int pad[2];
+    unsigned int n_list1;   // codewords that need the other four min-sum factors
+    unsigned int next_z;    // phase-0 work queue head
 };
+
+// result of decoding one codeword's UNMODIFIED LLRs with factor kFactors[f]
+constexpr int kNumFactors = 5;
+__device__ __constant__ float kFactors[kNumFactors] = {0.9375f, 0.875f, 0.75f, 0.625f, 0.5f};
+struct CwResult {
+    uint8_t ok[kNumFactors];
+    uint8_t have[kNumFactors - 2];   // padding / debug
+    uint16_t iters[kNumFactors];
+};  // 18 bytes
 
 struct FastDecodeArgs {
     FastCode c;
@@ -236,6 +246,9 @@ struct FastDecodeArgs {
     DecodeCtl* ctl;
     unsigned int* entries;   // [4*n_frames]  frame*4 + cw
     unsigned int* best;      // [4*n_frames]  first successful cascade attempt (0..33) or 0xFFFFFFFF
+    unsigned int* list1;     // [4*n_frames]  frame*4 + cw needing factors 1..4
+    CwResult* res;           // [4*n_frames]
+    uint8_t* res_bytes;      // [4*n_frames][5][bytes_per_cw]
 };
 
 template <class S>
@@ -247,65 +260,100 @@ __device__ inline void fast_gather_llr(FastState<S>& st, const FastCode& c, cons
     for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? fl[gather[cw * 648 + c.k + i]] : 0.0f; }
 }
 
-// ------------------------------------------------------------------------------------------------ kernel D1
-// primary decode + phase 0 + decoder-factor chain; 4 waves = the 4 codewords of a frame
+// decode codeword `fc` (= frame*4 + cw) with factor index f and record the result
 template <class S>
-__global__ __launch_bounds__(256) void fast_primary_kernel(FastDecodeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, float* msg, uint8_t* hb, unsigned fc, int f, int lane) {
     const FastCode& c = A.c;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frame = blockIdx.x;
-    const int wb = fast_wave_lds_bytes(c.m);
-    float* msg = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * wb);
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
-    volatile int* res = reinterpret_cast<volatile int*>(smem + 4 * static_cast<size_t>(wb));  // [4][2]
+    fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
+    bool ok;
+    int it = fast_decode(st, c, msg, hb, kFactors[f], c.max_iter, lane, &ok);
+    if (ok) fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), A.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw,
+                      c.bytes_per_cw, lane);
+    if (lane == 0) { A.res[fc].ok[f] = ok ? 1 : 0; A.res[fc].iters[f] = static_cast<uint16_t>(it); }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel P
+// first decode of every codeword (factor 0.9375): one single-wave workgroup per codeword, so the
+// hardware dispatcher balances converging (few iterations) and hopeless (80 iterations) codewords.
+template <class S>
+__global__ __launch_bounds__(64) void fast_primary_kernel(FastDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    float* msg = reinterpret_cast<float*>(smem);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(A.c.m));
     FastState<S> st;
-    fast_load_tables(st, c, lane);
-    fast_gather_llr(st, c, A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, wave, lane);
-    bool ok = false, p_ok = false, p0_ok = false;
-    int iters = 0, attempts = 0;
-    auto primary_and_phase0 = [&](float f_before) {
-        attempts = 1;
-        iters = fast_decode(st, c, msg, hb, f_before, c.max_iter, lane, &ok);
-        p_ok = ok; p0_ok = false;
-        if (!ok && (A.flags & RIA_DECODE_PHASE0)) {
-            const float f0[4] = {0.875f, 0.75f, 0.625f, 0.5f};
-            for (int t = 0; t < 4 && !ok; ++t) {
-                bool k2; attempts++;
-                int it = fast_decode(st, c, msg, hb, f0[t], c.max_iter, lane, &k2);
-                if (k2) { ok = true; iters = it; }
-            }
-            p0_ok = ok;
-        }
-        if (lane == 0) { res[wave * 2 + 0] = p_ok; res[wave * 2 + 1] = p0_ok; }
-    };
-    primary_and_phase0(0.9375f);
-    __syncthreads();
-    float f = 0.9375f;   // decoder-factor chain across the frame's codewords (see ldpc_kernels.hip.h)
+    fast_load_tables(st, A.c, lane);
+    fast_unit(st, A, msg, hb, blockIdx.x, 0, lane);
+}
+
+// per frame: every codeword at or after the first one whose first decode failed may need the other
+// four factors (phase 0 itself, or a first decode that inherits factor 0.875 through the chain)
+__global__ void fast_mark_kernel(FastDecodeArgs A) {
+    int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= A.n_frames) return;
+    if (!(A.flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB))) return;
+    bool failed = false;
     for (int cw = 0; cw < 4; ++cw) {
-        if (cw > 0) {
-            if (wave == cw && f != 0.9375f) primary_and_phase0(f);
-            __syncthreads();
-        }
-        bool pk = res[cw * 2 + 0] != 0, p0k = res[cw * 2 + 1] != 0;
-        if (!pk) {
-            if (A.flags & RIA_DECODE_PHASE0) f = 0.9375f;
-            if (!p0k && (A.flags & RIA_DECODE_PERTURB)) f = 0.875f;
-        }
+        unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
+        failed = failed || !A.res[fc].ok[0];
+        if (failed) A.list1[atomicAdd(&A.ctl->n_list1, 1u)] = fc;
     }
-    const int bpc = c.bytes_per_cw;
-    uint8_t* out = A.info_out + (static_cast<size_t>(frame) * 4 + wave) * bpc;
-    if (ok) fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), out, bpc, lane);
-    else for (int b = lane; b < bpc; b += 64) out[b] = 0;
-    if (lane == 0) {
-        ria_decode_status* s = A.status + frame;
-        s->cw_ok[wave] = ok ? 1 : 0;
-        s->iterations[wave] = static_cast<uint16_t>(iters);
-        s->attempts[wave] = static_cast<uint8_t>(attempts);
-        if (!ok && (A.flags & RIA_DECODE_PERTURB)) {
-            unsigned int e = atomicAdd(&A.ctl->n_entries, 1u);
-            A.entries[e] = static_cast<unsigned>(frame) * 4u + static_cast<unsigned>(wave);
-            A.best[e] = 0xFFFFFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel Z
+// one single-wave workgroup per (list1 entry, factor 1..4); the grid is sized for the worst case and
+// surplus workgroups exit at once (the list length is only known on the device)
+template <class S>
+__global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const unsigned u = blockIdx.x;
+    if (u >= A.ctl->n_list1 * 4u) return;
+    float* msg = reinterpret_cast<float*>(smem);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(A.c.m));
+    FastState<S> st;
+    fast_load_tables(st, A.c, lane);
+    fast_unit(st, A, msg, hb, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
+}
+
+// ------------------------------------------------------------------------------------------------ chain
+// One thread per frame replays the reference's sequential bookkeeping over the result table:
+// ONE decoder object serves the 4 codewords in order; its factor is restored to 0.9375 only after
+// phase 0 and left at 0.875 by phases 1-2 (frame_v2.cpp:1359-1361,1412,1447,1470), so a codeword that
+// follows one that needed phase >= 1 makes its FIRST decode at 0.875.
+__global__ void fast_chain_kernel(FastDecodeArgs A) {
+    int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= A.n_frames) return;
+    const int bpc = A.c.bytes_per_cw;
+    int f = 0;  // index into kFactors of the decoder's current factor (0 -> 0.9375, 1 -> 0.875)
+    ria_decode_status* s = A.status + frame;
+    for (int cw = 0; cw < 4; ++cw) {
+        const unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
+        const CwResult r = A.res[fc];
+        int accept = -1, attempts = 1, iters = r.iters[f];
+        if (r.ok[f]) accept = f;
+        else {
+            if (A.flags & RIA_DECODE_PHASE0) {
+                for (int t = 1; t <= 4 && accept < 0; ++t) { attempts++; if (r.ok[t]) { accept = t; iters = r.iters[t]; } }
+                f = 0;
+            }
+            if (accept < 0 && (A.flags & RIA_DECODE_PERTURB)) {
+                f = 1;
+                unsigned e = atomicAdd(&A.ctl->n_entries, 1u);
+                A.entries[e] = fc;
+                A.best[e] = 0xFFFFFFFFu;
+            }
         }
+        uint8_t* out = A.info_out + static_cast<size_t>(fc) * bpc;
+        if (accept >= 0) {
+            const uint8_t* src = A.res_bytes + (static_cast<size_t>(fc) * kNumFactors + accept) * bpc;
+            for (int b = 0; b < bpc; ++b) out[b] = src[b];
+        } else {
+            for (int b = 0; b < bpc; ++b) out[b] = 0;
+        }
+        s->cw_ok[cw] = accept >= 0 ? 1 : 0;
+        s->iterations[cw] = static_cast<uint16_t>(iters);
+        s->attempts[cw] = static_cast<uint8_t>(attempts);
     }
 }
 

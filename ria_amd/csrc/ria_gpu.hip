@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <atomic>
@@ -43,6 +44,9 @@ struct ria_gpu {
     DecodeCtl* d_ctl = nullptr;           // cascade work-list control block
     unsigned int* d_entries = nullptr;    // [4 * ws_frames]
     unsigned int* d_best = nullptr;       // [4 * ws_frames]
+    unsigned int* d_list1 = nullptr;      // [4 * ws_frames]
+    CwResult* d_res = nullptr;            // [4 * ws_frames]
+    uint8_t* d_res_bytes = nullptr;       // [4 * ws_frames][5][bytes_per_cw]
     int ws_frames = 0;
     Crc16Tables crc;
 };
@@ -108,13 +112,16 @@ static bool shape_fits(int rate, const LdpcCode& c) {
 }
 static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     if (n_frames <= h->ws_frames && h->d_ctl) return hipSuccess;
-    if (h->d_entries) (void)hipFree(h->d_entries);
-    if (h->d_best) (void)hipFree(h->d_best);
-    h->d_entries = h->d_best = nullptr;
+    for (void* p_ : {(void*)h->d_entries, (void*)h->d_best, (void*)h->d_list1, (void*)h->d_res, (void*)h->d_res_bytes})
+        if (p_) (void)hipFree(p_);
+    h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr;
     hipError_t e;
     if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), sizeof(DecodeCtl))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_entries), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_best), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_list1), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_res), static_cast<size_t>(n_frames) * 4 * sizeof(CwResult))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_res_bytes), static_cast<size_t>(n_frames) * 4 * kNumFactors * h->geo.bytes_per_codeword)) != hipSuccess) return e;
     h->ws_frames = n_frames;
     return hipSuccess;
 }
@@ -122,7 +129,8 @@ static void set_fast_attributes(int rate, int m) {
     dispatch_shape(rate, [&](auto s) {
         using S = decltype(s);
         int wb = fast_wave_lds_bytes(m);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_primary_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * wb + 64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_primary_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_finalize_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
@@ -297,7 +305,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
                     h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
-                    h->d_ctl, h->d_entries, h->d_best};
+                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -447,20 +455,41 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.ctl = h->d_ctl;
     A.entries = h->d_entries;
     A.best = h->d_best;
+    A.list1 = h->d_list1;
+    A.res = h->d_res;
+    A.res_bytes = h->d_res_bytes;
     if ((e = hipMemsetAsync(h->d_ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const int wb = fast_wave_lds_bytes(h->fast.m);
+    static const bool dbg = getenv("RIA_DEBUG_SYNC") != nullptr;   // stage-by-stage sync + trace on stderr
+    auto stage = [&](const char* name) {
+        if (!dbg) return;
+        hipError_t e2 = hipStreamSynchronize(s);
+        fprintf(stderr, "[ria_gpu] %s: %s\n", name, hipGetErrorString(e2));
+        fflush(stderr);
+    };
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(fast_primary_kernel<S>, dim3(n_frames), dim3(256), 4 * wb + 64, s, A);
+        hipLaunchKernelGGL(fast_primary_kernel<S>, dim3(n_frames * 4), dim3(64), wb, s, A);
+        stage("primary");
+        hipLaunchKernelGGL(fast_mark_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
+        stage("mark");
+        if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB))
+            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(n_frames * 16), dim3(64), wb, s, A);
+        stage("phase0");
+        hipLaunchKernelGGL(fast_chain_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
+        stage("chain");
         if (flags & RIA_DECODE_PERTURB) {
             // persistent waves over the device-side work list; sized to fill the chip (256 CUs x 12)
             hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(3072), dim3(64), wb, s, A);
+            stage("cascade");
             hipLaunchKernelGGL(fast_finalize_kernel<S>, dim3(2048), dim3(64), wb, s, A);
+            stage("finalize");
         }
     });
     hipLaunchKernelGGL(frame_validate_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, s, info_out_dev,
                        h->geo.bytes_per_codeword, n_frames, A.crc_bit, A.crc_init, status_dev);
+    stage("validate");
     return RIA_OK;
 }
 
