@@ -4,6 +4,7 @@
 // Each builder cites the reference routine whose result it must equal; tests compare the uploaded
 // tables against the oracle's.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <random>
@@ -209,6 +210,57 @@ inline LdpcCode build_ldpc(int rate) {  // ldpc_decoder.cpp:21-36, :65-138 (enco
         for (size_t d = 0; d < cols[j].size(); ++d) c.col_slot[d * c.n + j] = cols[j][d];
     }
     return c;
+}
+
+// ---------------------------------------------------------------- LDPC tables for the wave decoder
+// Rows are re-ordered by decreasing degree so that the 64 rows one wavefront processes together in a
+// "round" have (nearly) the same number of edges; position p = 64*round + lane handles check perm[p].
+// The arithmetic is unaffected: variable sums still run in ascending ORIGINAL check order.
+struct FastTables {
+    int k = 0, m = 0, n_rounds = 0, n_col_rounds = 0, max_col_deg = 0;
+    std::vector<uint16_t> perm;        // [m] position -> check index
+    std::vector<uint8_t> row_ne;       // [m] information edges of the check at position p
+    std::vector<uint16_t> row_var;     // [6][m] information variable of slot s at position p (0 if unused)
+    std::vector<uint8_t> col_deg;      // [k]
+    std::vector<uint16_t> col_slot;    // [max_col_deg][k] slot word index s*m + p, ascending check order
+    uint8_t round_ne[8] = {0};         // max information edges per row round (wave-uniform loop bounds)
+    uint8_t round_cd[16] = {0};        // max column degree per column round
+};
+
+inline FastTables build_fast_tables(const LdpcCode& c) {
+    FastTables t;
+    t.k = c.k; t.m = c.m;
+    const int k = c.k, m = c.m;
+    t.perm.resize(m);
+    for (int i = 0; i < m; ++i) t.perm[i] = static_cast<uint16_t>(i);
+    std::stable_sort(t.perm.begin(), t.perm.end(), [&](uint16_t a, uint16_t b) { return c.rows[a].size() > c.rows[b].size(); });
+    std::vector<int> pos(m);
+    for (int p = 0; p < m; ++p) pos[t.perm[p]] = p;
+    t.row_ne.assign(m, 0);
+    t.row_var.assign(static_cast<size_t>(6) * m, 0);
+    t.n_rounds = (m + 63) / 64;
+    for (int p = 0; p < m; ++p) {
+        const auto& row = c.rows[t.perm[p]];
+        int ne = static_cast<int>(row.size()) - 1;  // last edge is the identity column k+i
+        t.row_ne[p] = static_cast<uint8_t>(ne);
+        for (int s = 0; s < ne; ++s) t.row_var[static_cast<size_t>(s) * m + p] = static_cast<uint16_t>(row[s]);
+        t.round_ne[p / 64] = std::max<uint8_t>(t.round_ne[p / 64], static_cast<uint8_t>(ne));
+    }
+    std::vector<std::vector<uint16_t>> cols(k);
+    for (int i = 0; i < m; ++i) {  // ascending original check index
+        const auto& row = c.rows[i];
+        for (size_t s = 0; s + 1 < row.size(); ++s) cols[row[s]].push_back(static_cast<uint16_t>(s * m + pos[i]));
+    }
+    for (auto& v : cols) t.max_col_deg = std::max(t.max_col_deg, static_cast<int>(v.size()));
+    t.col_deg.assign(k, 0);
+    t.col_slot.assign(static_cast<size_t>(std::max(1, t.max_col_deg)) * k, 0);
+    t.n_col_rounds = (k + 63) / 64;
+    for (int j = 0; j < k; ++j) {
+        t.col_deg[j] = static_cast<uint8_t>(cols[j].size());
+        t.round_cd[j / 64] = std::max<uint8_t>(t.round_cd[j / 64], t.col_deg[j]);
+        for (size_t d = 0; d < cols[j].size(); ++d) t.col_slot[d * k + j] = cols[j][d];
+    }
+    return t;
 }
 
 // ---------------------------------------------------------------- RX gather (both de-interleavers folded)

@@ -29,57 +29,79 @@ constexpr int kInfoSlots = 6;  // information edges per check (max_check_degree,
 // DV max information-column degree.
 template <int RR_, int IR_, int DV_>
 struct CodeShape { static constexpr int RR = RR_, IR = IR_, DV = DV_; };
-using ShapeR12 = CodeShape<6, 6, 6>;    // R1/2 and R1/3: m = 324, k = 324, dv <= 6
+using ShapeR12 = CodeShape<6, 6, 5>;    // R1/2: m = 324, k = 324, dv <= 5
+using ShapeR13 = CodeShape<6, 6, 6>;    // R1/3 (same k, m; H seeded differently): dv <= 6
 using ShapeR14 = CodeShape<8, 3, 13>;   // m = 486, k = 162
 using ShapeR23 = CodeShape<4, 7, 3>;    // m = 216, k = 432
 using ShapeR34 = CodeShape<3, 8, 3>;    // m = 162, k = 486
 using ShapeR56 = CodeShape<2, 9, 3>;    // m = 108, k = 540
 
+// Device view of host_tables.hpp FastTables (rows sorted by degree: position p = 64*round + lane).
 struct FastCode {
     int k, m, max_iter, bytes_per_cw;
-    const uint8_t* row_deg;    // [m]  total degree incl. the identity edge
-    const uint8_t* col_deg;    // [n]
-    const uint16_t* col_slot;  // [max_col_deg][n] slot addresses s*m + i, ascending check order
-    int n;
+    const uint16_t* perm;      // [m] position -> check index
+    const uint8_t* row_ne;     // [m] information edges at position p
+    const uint16_t* row_var;   // [6][m] information variable of slot s at position p
+    const uint8_t* col_deg;    // [k]
+    const uint16_t* col_slot;  // [dv][k] slot word index s*m + p, ascending check order
+    uint8_t round_ne[8];       // wave-uniform loop bounds
+    uint8_t round_cd[16];
 };
 
-__host__ __device__ inline int fast_msg_words(int m) { int w = kInfoSlots * m; return w > 1296 ? w : 1296; }
-__host__ __device__ inline int fast_wave_lds_bytes(int m) { return fast_msg_words(m) * 4 + ((kInfoSlots * m + 15) & ~15) + 16; }
+// LDS per wave (words): c2v messages [6][m] | total LLR of the information columns [k] | 64 dummy words
+// (stores of inactive edges are redirected there, one word per lane, to keep the loop branch-free).
+// The same region doubles as mt19937 state + 648 normals during the retry cascade (>= 1296 words).
+__host__ __device__ inline int fast_tot_word(int m) { return kInfoSlots * m; }
+__host__ __device__ inline int fast_dummy_word(int m, int k) { return kInfoSlots * m + k; }
+__host__ __device__ inline int fast_wave_lds_bytes(int m, int k = 324) {
+    int w = kInfoSlots * m + k + 64;
+    if (w < 1296) w = 1296;
+    return (w * 4 + 15) & ~15;
+}
 
 template <class S>
 struct FastState {
-    // tables (loaded once)
-    uint32_t rdeg;                 // 4 bits per row round
-    uint32_t cdeg[(S::IR + 7) / 8];  // 4 bits per information column round
-    uint32_t slot[(S::IR * S::DV + 1) / 2];  // packed u16 slot addresses [r][d]
+    // tables (loaded once per wave): BYTE addresses inside the wave's LDS region, packed 2 x u16
+    uint32_t rne;                                // 4 bits per row round: information edges (0 beyond m)
+    uint32_t cdeg[(S::IR + 7) / 8];              // 4 bits per column round
+    uint32_t rvar[(S::RR * kInfoSlots + 1) / 2]; // byte address of tot[var] for (round, slot)
+    uint32_t cslot[(S::IR * S::DV + 1) / 2];     // byte address of the c2v slot for (round, d)
     // decoder input of the current attempt
-    float li[S::IR];               // information-column LLRs
-    float lp[S::RR];               // identity-column LLRs
+    float li[S::IR];               // information-column LLRs (column j = lane + 64 r)
+    float lp[S::RR];               // identity-column LLRs   (column k + perm[lane + 64 r])
     // running state
     float pv[S::RR];               // v2c of the identity edges
     uint32_t phard;                // hard bits of the identity columns (bit r)
     uint32_t ihard;                // hard bits of the information columns (bit r)
 };
 
-template <class S>
-__device__ __forceinline__ int get_slot(const FastState<S>& st, int r, int d) {
-    uint32_t w = st.slot[(r * S::DV + d) >> 1];
-    return ((r * S::DV + d) & 1) ? (w >> 16) : (w & 0xffffu);
+template <int PER, class T>
+__device__ __forceinline__ uint32_t unpack16(const T& arr, int idx) {
+    uint32_t w = arr[idx >> 1];
+    return (idx & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
 template <class S>
 __device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, int lane) {
-    st.rdeg = 0;
+    st.rne = 0;
 #pragma unroll
-    for (int r = 0; r < S::RR; ++r) {
-        int i = lane + 64 * r;
-        uint32_t d = (i < c.m) ? c.row_deg[i] : 0u;
-        st.rdeg |= d << (4 * r);
-    }
+    for (int w = 0; w < (S::RR * kInfoSlots + 1) / 2; ++w) st.rvar[w] = 0;
 #pragma unroll
     for (int w = 0; w < (S::IR + 7) / 8; ++w) st.cdeg[w] = 0;
 #pragma unroll
-    for (int w = 0; w < (S::IR * S::DV + 1) / 2; ++w) st.slot[w] = 0;
+    for (int w = 0; w < (S::IR * S::DV + 1) / 2; ++w) st.cslot[w] = 0;
+    const uint32_t tot_base = static_cast<uint32_t>(fast_tot_word(c.m)) * 4u;
+#pragma unroll
+    for (int r = 0; r < S::RR; ++r) {
+        int p = lane + 64 * r;
+        uint32_t ne = (p < c.m) ? c.row_ne[p] : 0u;
+        st.rne |= ne << (4 * r);
+#pragma unroll
+        for (int s = 0; s < kInfoSlots; ++s) {
+            uint32_t a = (s < static_cast<int>(ne)) ? tot_base + 4u * c.row_var[s * c.m + p] : tot_base;
+            st.rvar[(r * kInfoSlots + s) >> 1] |= a << (((r * kInfoSlots + s) & 1) * 16);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < S::IR; ++r) {
         int j = lane + 64 * r;
@@ -87,25 +109,38 @@ __device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, int
         st.cdeg[r >> 3] |= d << (4 * (r & 7));
 #pragma unroll
         for (int e = 0; e < S::DV; ++e) {
-            uint32_t a = (e < static_cast<int>(d)) ? c.col_slot[e * c.n + j] : 0u;
-            st.slot[(r * S::DV + e) >> 1] |= a << (((r * S::DV + e) & 1) * 16);
+            uint32_t a = (e < static_cast<int>(d)) ? 4u * c.col_slot[e * c.k + j] : 0u;
+            st.cslot[(r * S::DV + e) >> 1] |= a << (((r * S::DV + e) & 1) * 16);
         }
     }
 }
 
+__device__ __forceinline__ float lds_f(const unsigned char* base, uint32_t off) { return *reinterpret_cast<const float*>(base + off); }
+__device__ __forceinline__ void lds_sf(unsigned char* base, uint32_t off, float v) { *reinterpret_cast<float*>(base + off) = v; }
+
 // Runs the decoder on the LLRs in st.li / st.lp.  Returns LDPCDecoder::lastIterations(); *ok = converged.
 // On return st.ihard holds the information hard bits of the accepted (or last) iteration.
+//
+// Message flow per iteration (same arithmetic as ldpc_decoder.cpp:176-236, different bookkeeping):
+//   check pass   for every edge: v2c = clamp(tot[var] - c2v_old) (iteration 0: v2c = llr), hard bit =
+//                tot[var] < 0 (-> syndrome of the PREVIOUS iteration for free), then the min-sum update
+//                written back to the edge's slot as c2v;
+//   column pass  tot[j] = llr[j] + sum of its c2v slots in ascending check order -> ONE store per column.
+// Integer tricks keep it exact: |x| of finite floats orders like the unsigned bit pattern, so min1/min2
+// use integer min/med3; "x < 0" is taken from a float compare so that -0.0 counts as positive exactly
+// like the reference's `if (msg < 0)`.
 template <class S>
-__device__ inline int fast_decode(FastState<S>& st, const FastCode& c, float* __restrict__ msg, uint8_t* __restrict__ hb,
+__device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned char* __restrict__ lds,
                                   float factor, int max_iter, int lane, bool* ok) {
     const int m = c.m;
-    // v2c := channel LLR on every edge
+    const uint32_t tot_base = static_cast<uint32_t>(fast_tot_word(m)) * 4u;
+    const uint32_t dummy = static_cast<uint32_t>(fast_dummy_word(m, c.k) + lane) * 4u;
+    const uint32_t kInfBits = 0x7f7fffffu;  // FLT_MAX, the reference's initial min_abs
+    // tot := channel LLR of the information columns
 #pragma unroll
     for (int r = 0; r < S::IR; ++r) {
-        int deg = (st.cdeg[r >> 3] >> (4 * (r & 7))) & 15;
-#pragma unroll
-        for (int d = 0; d < S::DV; ++d)
-            if (d < deg) msg[get_slot(st, r, d)] = st.li[r];
+        int j = lane + 64 * r;
+        lds_sf(lds, (j < c.k) ? tot_base + 4u * j : dummy, st.li[r]);
     }
 #pragma unroll
     for (int r = 0; r < S::RR; ++r) st.pv[r] = st.lp[r];
@@ -115,83 +150,108 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, float* __
     bool success = false;
     for (;; ++it) {
         const bool last_check_only = (it == max_iter);  // trailing pass: syndrome of the final iteration
-        int syn = 0;
+        const bool first = (it == 0);
+        // Keep the per-lane tables opaque inside the loop: otherwise LICM hoists all 36 unpacked
+        // addresses and 36 lane masks (64-bit SGPR pairs) out of it and the kernel drowns in spills.
+        uint32_t rne = st.rne;
+        asm volatile("" : "+v"(rne));
+        uint32_t syn = 0;
 #pragma unroll
         for (int r = 0; r < S::RR; ++r) {
-            const int i = lane + 64 * r;
-            const int deg = (st.rdeg >> (4 * r)) & 15;  // 0 for rows beyond m
-            if (deg > 0) {
-                float v[kInfoSlots + 1];
-                float min1 = 3.402823466e+38f, min2 = 3.402823466e+38f;
-                int arg = -1, neg = 0, par = (st.phard >> r) & 1;
+            const int p = lane + 64 * r;
+            // 6-bit activity pattern of this row's slots (ones for s < ne), rows beyond m: none
+            uint32_t abits = (1u << ((rne >> (4 * r)) & 15u)) - 1u;
+            const uint32_t vmask = static_cast<uint32_t>((p - m) >> 31); // all ones for p < m
+            const uint32_t srow = 4u * static_cast<uint32_t>(p) & vmask;
+            // (opaque per round: the unpacked addresses must not be hoisted out of their round)
+#pragma unroll
+            for (int w = (r * kInfoSlots) / 2; w <= (r * kInfoSlots + kInfoSlots - 1) / 2; ++w) asm volatile("" : "+v"(st.rvar[w]));
+            // issue all 12 LDS reads of the round back to back (inactive slots read valid dummy addresses)
+            float t[kInfoSlots], cold[kInfoSlots];
+#pragma unroll
+            for (int s = 0; s < kInfoSlots; ++s) {
+                t[s] = lds_f(lds, unpack16<0>(st.rvar, r * kInfoSlots + s));
+                cold[s] = lds_f(lds, srow + 4u * s * m);
+            }
+            uint32_t ab[kInfoSlots], sb[kInfoSlots], act[kInfoSlots];
+            uint32_t min1 = kInfBits, min2 = kInfBits, sgn = 0, par = (st.phard >> r) & 1u;
+#pragma unroll
+            for (int s = 0; s < kInfoSlots; ++s) {
+                // sign-extended bit s of abits: all ones when the slot is active (kept opaque so that the
+                // compiler does not turn the masks back into 64-bit SGPR lane masks)
+                int am;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(am) : "v"(abits), "n"(s));
+                act[s] = static_cast<uint32_t>(am);
+                float v = t[s] - cold[s];
+                v = (v < 50.0f) ? v : 50.0f;
+                v = (-50.0f < v) ? v : -50.0f;
+                v = first ? t[s] : v;
+                par ^= ((t[s] < 0.0f) ? 1u : 0u) & act[s];
+                sb[s] = ((v < 0.0f) ? 0x80000000u : 0u) & act[s];
+                sgn ^= sb[s];
+                const uint32_t a = f2u(v) & 0x7fffffffu;
+                ab[s] = (a & act[s]) | (kInfBits & ~act[s]);
+                const uint32_t lo = min(ab[s], min1);
+                const uint32_t hi = max(ab[s], min1);
+                min2 = min(hi, min2);
+                min1 = lo;
+            }
+            syn |= par & vmask;
+            if (!last_check_only) {   // wave-uniform
+                const float xp = st.pv[r];                // identity edge: the last edge of the row
+                const uint32_t sp = (xp < 0.0f) ? 0x80000000u : 0u;
+                sgn ^= sp;
+                const uint32_t ap = f2u(xp) & 0x7fffffffu;
+                {
+                    const uint32_t lo = min(ap, min1);
+                    const uint32_t hi = max(ap, min1);
+                    min2 = min(hi, min2);
+                    min1 = lo;
+                }
 #pragma unroll
                 for (int s = 0; s < kInfoSlots; ++s) {
-                    if (s < deg - 1) {
-                        float x = msg[s * m + i];
-                        par ^= hb[s * m + i];
-                        v[s] = x;
-                        neg ^= (x < 0.0f) ? 1 : 0;
-                        float a = fabs_(x);
-                        if (a < min1) { min2 = min1; min1 = a; arg = s; }
-                        else if (a < min2) { min2 = a; }
-                    }
+                    // min over the OTHER edges: min2 if this edge holds the minimum (ties: min2 == min1)
+                    const uint32_t mn = (ab[s] == min1) ? min2 : min1;
+                    const float cv = u2f(mn | (sgn ^ sb[s])) * factor;   // (sign * min_abs) * factor
+                    const uint32_t am = act[s] & vmask;
+                    const uint32_t addr = ((srow + 4u * s * m) & am) | (dummy & ~am);
+                    lds_sf(lds, addr, cv);
                 }
-                syn |= par;
-                if (!last_check_only) {
-                    {   // identity edge (always the last one of the row: reference edge order)
-                        float x = st.pv[r];
-                        v[kInfoSlots] = x;
-                        neg ^= (x < 0.0f) ? 1 : 0;
-                        float a = fabs_(x);
-                        if (a < min1) { min2 = min1; min1 = a; arg = kInfoSlots; }
-                        else if (a < min2) { min2 = a; }
-                    }
-#pragma unroll
-                    for (int s = 0; s < kInfoSlots; ++s) {
-                        if (s < deg - 1) {
-                            int sg = neg ^ ((v[s] < 0.0f) ? 1 : 0);
-                            float mn = (s == arg) ? min2 : min1;
-                            msg[s * m + i] = (sg ? -mn : mn) * factor;
-                        }
-                    }
-                    {   // identity column: degree 1, so total = llr + c2v and v2c = clamp(total - c2v)
-                        int sg = neg ^ ((v[kInfoSlots] < 0.0f) ? 1 : 0);
-                        float mn = (arg == kInfoSlots) ? min2 : min1;
-                        float c2v = (sg ? -mn : mn) * factor;
-                        float tot = st.lp[r] + c2v;
-                        float x = tot - c2v;
-                        x = (x < 50.0f) ? x : 50.0f;
-                        x = (-50.0f < x) ? x : -50.0f;
-                        st.pv[r] = x;
-                        st.phard = (st.phard & ~(1u << r)) | ((tot < 0.0f) ? (1u << r) : 0u);
-                    }
+                {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
+                    const uint32_t mn = (ap == min1) ? min2 : min1;
+                    const float c2v = u2f(mn | (sgn ^ sp)) * factor;
+                    const float tot = st.lp[r] + c2v;
+                    float y = tot - c2v;
+                    y = (y < 50.0f) ? y : 50.0f;
+                    y = (-50.0f < y) ? y : -50.0f;
+                    st.pv[r] = u2f(f2u(y) & vmask);
+                    st.phard = (st.phard & ~(1u << r)) | (((tot < 0.0f) ? (1u << r) : 0u) & vmask);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);   // one round at a time: keeps the live set (VGPRs) small
         }
         if (it > 0 && __ballot(syn != 0) == 0ull) { success = true; --it; break; }
         if (last_check_only) break;
         wave_sync();
-        // information columns
+        // information columns: tot = llr + sum of c2v in ascending check order
+        uint32_t cd0 = st.cdeg[0];
+        asm volatile("" : "+v"(cd0));
 #pragma unroll
         for (int r = 0; r < S::IR; ++r) {
-            int deg = (st.cdeg[r >> 3] >> (4 * (r & 7))) & 15;
+            const int j = lane + 64 * r;
+            const int deg = static_cast<int>((((r < 8) ? cd0 : st.cdeg[r >> 3]) >> (4 * (r & 7))) & 15u);
             float tot = st.li[r];
+#pragma unroll
+            for (int w = (r * S::DV) / 2; w <= (r * S::DV + S::DV - 1) / 2; ++w) asm volatile("" : "+v"(st.cslot[w]));
             float cv[S::DV];
 #pragma unroll
-            for (int d = 0; d < S::DV; ++d)
-                if (d < deg) { cv[d] = msg[get_slot(st, r, d)]; tot += cv[d]; }
-            int hbit = (tot < 0.0f) ? 1 : 0;
+            for (int d = 0; d < S::DV; ++d) cv[d] = lds_f(lds, unpack16<0>(st.cslot, r * S::DV + d));
 #pragma unroll
-            for (int d = 0; d < S::DV; ++d)
-                if (d < deg) {
-                    int a = get_slot(st, r, d);
-                    float x = tot - cv[d];
-                    x = (x < 50.0f) ? x : 50.0f;
-                    x = (-50.0f < x) ? x : -50.0f;
-                    msg[a] = x;
-                    hb[a] = static_cast<uint8_t>(hbit);
-                }
-            st.ihard = (st.ihard & ~(1u << r)) | (static_cast<uint32_t>(hbit) << r);
+            for (int d = 0; d < S::DV; ++d) tot = (d < deg) ? tot + cv[d] : tot;
+            const uint32_t jm = static_cast<uint32_t>((j - c.k) >> 31);
+            lds_sf(lds, ((tot_base + 4u * j) & jm) | (dummy & ~jm), tot);
+            st.ihard = (st.ihard & ~(1u << r)) | ((tot < 0.0f) ? (1u << r) : 0u);
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);
         }
         wave_sync();
     }
@@ -257,17 +317,17 @@ __device__ inline void fast_gather_llr(FastState<S>& st, const FastCode& c, cons
 #pragma unroll
     for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? fl[gather[cw * 648 + j]] : 0.0f; }
 #pragma unroll
-    for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? fl[gather[cw * 648 + c.k + i]] : 0.0f; }
+    for (int r = 0; r < S::RR; ++r) { int p = lane + 64 * r; st.lp[r] = (p < c.m) ? fl[gather[cw * 648 + c.k + c.perm[p]]] : 0.0f; }
 }
 
 // decode codeword `fc` (= frame*4 + cw) with factor index f and record the result
 template <class S>
-__device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, float* msg, uint8_t* hb, unsigned fc, int f, int lane) {
+__device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, unsigned char* lds, unsigned fc, int f, int lane) {
     const FastCode& c = A.c;
     fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
     bool ok;
-    int it = fast_decode(st, c, msg, hb, kFactors[f], c.max_iter, lane, &ok);
-    if (ok) fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), A.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw,
+    int it = fast_decode(st, c, lds, kFactors[f], c.max_iter, lane, &ok);
+    if (ok) fast_pack(st, c, lds, A.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw,
                       c.bytes_per_cw, lane);
     if (lane == 0) { A.res[fc].ok[f] = ok ? 1 : 0; A.res[fc].iters[f] = static_cast<uint16_t>(it); }
 }
@@ -279,11 +339,9 @@ template <class S>
 __global__ __launch_bounds__(64) void fast_primary_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    float* msg = reinterpret_cast<float*>(smem);
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(A.c.m));
     FastState<S> st;
     fast_load_tables(st, A.c, lane);
-    fast_unit(st, A, msg, hb, blockIdx.x, 0, lane);
+    fast_unit(st, A, smem, blockIdx.x, 0, lane);
 }
 
 // per frame: every codeword at or after the first one whose first decode failed may need the other
@@ -309,11 +367,9 @@ __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     const int lane = threadIdx.x;
     const unsigned u = blockIdx.x;
     if (u >= A.ctl->n_list1 * 4u) return;
-    float* msg = reinterpret_cast<float*>(smem);
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(A.c.m));
     FastState<S> st;
     fast_load_tables(st, A.c, lane);
-    fast_unit(st, A, msg, hb, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
+    fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
 }
 
 // ------------------------------------------------------------------------------------------------ chain
@@ -375,7 +431,7 @@ __device__ inline float fast_perturb(FastState<S>& st, const FastCode& c, const 
 #pragma unroll
     for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? tf(base_i[r], normal[j]) : 0.0f; }
 #pragma unroll
-    for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? tf(base_p[r], normal[c.k + i]) : 0.0f; }
+    for (int r = 0; r < S::RR; ++r) { int p = lane + 64 * r; st.lp[r] = (p < c.m) ? tf(base_p[r], normal[c.k + c.perm[p]]) : 0.0f; }
     wave_sync();
     return factor;
 }
@@ -398,7 +454,6 @@ __global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
     const FastCode& c = A.c;
     const int lane = threadIdx.x;
     float* msg = reinterpret_cast<float*>(smem);
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
     const unsigned int n_entries = A.ctl->n_entries;
     const unsigned int total = n_entries * 34u;
     if (total == 0) return;
@@ -423,7 +478,7 @@ __global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
         uint32_t h = fast_hash16(st);
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
-        (void)fast_decode(st, c, msg, hb, factor, c.max_iter, lane, &ok);
+        (void)fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
         if (ok && lane == 0) atomicMin(&A.best[e], a);
     }
 }
@@ -437,7 +492,6 @@ __global__ __launch_bounds__(64) void fast_finalize_kernel(FastDecodeArgs A) {
     const int lane = threadIdx.x;
     const unsigned int n_entries = A.ctl->n_entries;
     float* msg = reinterpret_cast<float*>(smem);
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
     for (unsigned int e = blockIdx.x; e < n_entries; e += gridDim.x) {
         const unsigned int fc = A.entries[e], frame = fc >> 2, cw = fc & 3;
         const unsigned int a = A.best[e];
@@ -457,8 +511,8 @@ __global__ __launch_bounds__(64) void fast_finalize_kernel(FastDecodeArgs A) {
         uint32_t h = fast_hash16(st);
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
-        int it = fast_decode(st, c, msg, hb, factor, c.max_iter, lane, &ok);
-        fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), A.info_out + (static_cast<size_t>(frame) * 4 + cw) * c.bytes_per_cw,
+        int it = fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
+        fast_pack(st, c, smem, A.info_out + (static_cast<size_t>(frame) * 4 + cw) * c.bytes_per_cw,
                   c.bytes_per_cw, lane);
         if (lane == 0) {
             s->cw_ok[cw] = ok ? 1 : 0;  // ok is true by construction
@@ -520,8 +574,6 @@ __global__ __launch_bounds__(64) void fast_rows_kernel(FastCode c, const float* 
                                                        uint16_t* __restrict__ iters_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    float* msg = reinterpret_cast<float*>(smem);
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + fast_msg_words(c.m));
     FastState<S> st;
     fast_load_tables(st, c, lane);
     const int nb = (c.k + 7) / 8;
@@ -530,10 +582,10 @@ __global__ __launch_bounds__(64) void fast_rows_kernel(FastCode c, const float* 
 #pragma unroll
         for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? l[j] : 0.0f; }
 #pragma unroll
-        for (int r = 0; r < S::RR; ++r) { int i = lane + 64 * r; st.lp[r] = (i < c.m) ? l[c.k + i] : 0.0f; }
+        for (int r = 0; r < S::RR; ++r) { int p = lane + 64 * r; st.lp[r] = (p < c.m) ? l[c.k + c.perm[p]] : 0.0f; }
         bool ok;
-        int it = fast_decode(st, c, msg, hb, factor, max_iter, lane, &ok);
-        fast_pack(st, c, reinterpret_cast<uint8_t*>(msg), out + static_cast<size_t>(cw) * nb, nb, lane);
+        int it = fast_decode(st, c, smem, factor, max_iter, lane, &ok);
+        fast_pack(st, c, smem, out + static_cast<size_t>(cw) * nb, nb, lane);
         if (lane == 0) { ok_out[cw] = ok ? 1 : 0; iters_out[cw] = static_cast<uint16_t>(it); }
     }
 }

@@ -41,6 +41,8 @@ struct ria_gpu {
     float* d_llr_ws = nullptr;            // max_batch * llrs_per_frame (fused path)
     LdpcDev ldpc_dev{};
     FastCode fast{};
+    FastTables ftab;
+    void* d_f_perm = nullptr; void* d_f_row_ne = nullptr; void* d_f_row_var = nullptr; void* d_f_col_deg = nullptr; void* d_f_col_slot = nullptr;
     DecodeCtl* d_ctl = nullptr;           // cascade work-list control block
     unsigned int* d_entries = nullptr;    // [4 * ws_frames]
     unsigned int* d_best = nullptr;       // [4 * ws_frames]
@@ -96,7 +98,8 @@ static void dispatch_shape(int rate, F&& f) {
         case RIA_RATE_2_3: f(ShapeR23{}); break;
         case RIA_RATE_3_4: f(ShapeR34{}); break;
         case RIA_RATE_5_6: f(ShapeR56{}); break;
-        default: f(ShapeR12{}); break;  // R1/2, R1/3 (k = m = 324)
+        case RIA_RATE_1_3: f(ShapeR13{}); break;
+        default: f(ShapeR12{}); break;
     }
 }
 static bool shape_fits(int rate, const LdpcCode& c) {
@@ -125,10 +128,10 @@ static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     h->ws_frames = n_frames;
     return hipSuccess;
 }
-static void set_fast_attributes(int rate, int m) {
+static void set_fast_attributes(int rate, int m, int k) {
     dispatch_shape(rate, [&](auto s) {
         using S = decltype(s);
-        int wb = fast_wave_lds_bytes(m);
+        int wb = fast_wave_lds_bytes(m, k);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_primary_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
@@ -239,7 +242,7 @@ static int run_crc_recovery(ria_gpu_handle h, const float* llr_dev, int llr_stri
         for (int at = 0; at < 4; ++at)
             dispatch_shape(h->cfg.code_rate, [&](auto sh) {
                 using S = decltype(sh);
-                hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(ncw2, 8192)), dim3(64), fast_wave_lds_bytes(h->fast.m), s,
+                hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(ncw2, 8192)), dim3(64), fast_wave_lds_bytes(h->fast.m, h->fast.k), s,
                                    h->fast, d_rows2, ncw2, h->geo.ldpc_max_iterations, rf[at],
                                    d_out + static_cast<size_t>(at) * ncw2 * nb, d_ok + static_cast<size_t>(at) * ncw2,
                                    d_it + static_cast<size_t>(at) * ncw2);
@@ -305,7 +308,8 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
                     h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
-                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes};
+                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
+                    h->d_f_perm, h->d_f_row_ne, h->d_f_row_var, h->d_f_col_deg, h->d_f_col_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -396,10 +400,22 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     L.col_deg = static_cast<const uint8_t*>(h->d_col_deg);
     L.col_slot = static_cast<const uint16_t*>(h->d_col_slot);
 
-    h->fast.k = L.k; h->fast.m = L.m; h->fast.n = L.n; h->fast.max_iter = L.max_iter; h->fast.bytes_per_cw = L.bytes_per_cw;
-    h->fast.row_deg = L.row_deg; h->fast.col_deg = L.col_deg; h->fast.col_slot = L.col_slot;
+    h->ftab = build_fast_tables(h->code);
+    CREATE_TRY(upload(&h->d_f_perm, h->ftab.perm));
+    CREATE_TRY(upload(&h->d_f_row_ne, h->ftab.row_ne));
+    CREATE_TRY(upload(&h->d_f_row_var, h->ftab.row_var));
+    CREATE_TRY(upload(&h->d_f_col_deg, h->ftab.col_deg));
+    CREATE_TRY(upload(&h->d_f_col_slot, h->ftab.col_slot));
+    h->fast.k = L.k; h->fast.m = L.m; h->fast.max_iter = L.max_iter; h->fast.bytes_per_cw = L.bytes_per_cw;
+    h->fast.perm = static_cast<const uint16_t*>(h->d_f_perm);
+    h->fast.row_ne = static_cast<const uint8_t*>(h->d_f_row_ne);
+    h->fast.row_var = static_cast<const uint16_t*>(h->d_f_row_var);
+    h->fast.col_deg = static_cast<const uint8_t*>(h->d_f_col_deg);
+    h->fast.col_slot = static_cast<const uint16_t*>(h->d_f_col_slot);
+    std::memcpy(h->fast.round_ne, h->ftab.round_ne, 8);
+    std::memcpy(h->fast.round_cd, h->ftab.round_cd, 16);
     if (!shape_fits(cfg->code_rate, h->code)) { ria_gpu_destroy(h); return RIA_ERR_UNSUPPORTED; }
-    set_fast_attributes(cfg->code_rate, L.m);
+    set_fast_attributes(cfg->code_rate, L.m, L.k);
     CREATE_TRY(ensure_decode_ws(h, h->cfg.max_batch));
     // dynamic LDS above 64 KiB must be opted into per kernel
     int frame_lds = 4 * ldpc_wave_lds_bytes(L.m) + kFrameSharedBytes;
@@ -429,7 +445,7 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
     HIP_TRY(h, hipSetDevice(h->device));
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), fast_wave_lds_bytes(h->fast.m),
+        hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), fast_wave_lds_bytes(h->fast.m, h->fast.k),
                            static_cast<hipStream_t>(stream), h->fast, llr_dev, n_cw, max_iterations, min_sum_factor,
                            out_dev, ok_dev, iters_dev);
     });
@@ -460,7 +476,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.res_bytes = h->d_res_bytes;
     if ((e = hipMemsetAsync(h->d_ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-    const int wb = fast_wave_lds_bytes(h->fast.m);
+    const int wb = fast_wave_lds_bytes(h->fast.m, h->fast.k);
     static const bool dbg = getenv("RIA_DEBUG_SYNC") != nullptr;   // stage-by-stage sync + trace on stderr
     auto stage = [&](const char* name) {
         if (!dbg) return;
