@@ -102,6 +102,7 @@ struct DemodArgs {
     float* llr_out;
     int llr_stride;
     ria_frame_status* status;  // nullable
+    unsigned long long* dbg;   // nullable: per-frame phase stamps (s_memtime), diagnostic builds of the bench only
 };
 
 // ---------------------------------------------------------------- complex helpers (reference semantics)
@@ -121,16 +122,37 @@ __device__ __forceinline__ float2 conj_(float2 a) { return make_float2(a.x, -a.y
 __device__ __forceinline__ float maxf_(float a, float b) { return (a < b) ? b : a; }  // std::max
 __device__ __forceinline__ float minf_(float a, float b) { return (b < a) ? b : a; }  // std::min
 
-// Left-to-right float sum over the lanes set in `mask` (ascending lane = the reference's loop order).
-// Lanes outside the mask must pass +0.0f (x + 0 == x bit-for-bit while the accumulator starts at +0).
-__device__ __forceinline__ float ordered_sum(float term, unsigned long long mask) {
-    float acc = 0.0f;
-    while (mask) {
-        int l = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), l));
+// Ordered (left-to-right) float sums, N at a time: the reference accumulates e.g. `cpe_sum += ...` in a
+// for-loop over carriers, and float addition is not associative, so the same order is kept.  Members
+// scatter their N terms to LDS rows compacted by ordinal (member o -> T[k][o]); lane k then adds row k
+// front to back (contiguous 16-byte LDS reads, `count` dependent adds) while the other N-1 sums run
+// in the neighbouring lanes; results are broadcast with readlane.
+// Non-members / ordinals >= count contribute nothing (the accumulator starts at +0 and never becomes -0).
+template <int N, int MAXC>
+__device__ __forceinline__ void ordered_sums(const float (&terms)[N], bool member, int ord, int count, float* T,
+                                             int lane, float (&out)[N]) {
+    static_assert(N <= 8 && MAXC % 4 == 0 && MAXC <= 64, "scratch is [8][64]");
+    if (member) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) T[k * 64 + ord] = terms[k];
     }
-    return acc;
+    wave_sync();
+    const float4* row = reinterpret_cast<const float4*>(T + (lane & 7) * 64);
+    float4 v[MAXC / 4];
+#pragma unroll
+    for (int q = 0; q < MAXC / 4; ++q) v[q] = row[q];
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < MAXC / 4; ++q) {
+        acc = (4 * q + 0 < count) ? acc + v[q].x : acc;
+        acc = (4 * q + 1 < count) ? acc + v[q].y : acc;
+        acc = (4 * q + 2 < count) ? acc + v[q].z : acc;
+        acc = (4 * q + 3 < count) ? acc + v[q].w : acc;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        out[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), k));
+    wave_sync();
 }
 __device__ __forceinline__ float lane_read(float v, int l) { return __shfl(v, l); }
 
@@ -333,53 +355,74 @@ __device__ __forceinline__ float2 hard_decision(float2 s, int mod) {  // channel
 }
 
 // ---------------------------------------------------------------- the frame kernel
-constexpr int kDemodThreads = 256;
-// LDS: 4 FFT tiles + Y[16+][64]; the LLR staging area aliases FFT tiles 1..3 (idle in phase E)
+constexpr int kDemodThreads = 64;   // ONE wavefront per frame: no workgroup barriers, no idle waves in phase E
+// LDS per frame: 1 FFT tile (8.7 KB) + Y[n_sym][64] bins + small shared state (~19 KB at 16 symbols)
 constexpr int kMaxSymbols = 40;  // 2 LTS + up to 38 data symbols (DBPSK R1/4 needs 2592/53 = 49 -> see launch check)
 
 struct DemodShared {
     float cfo, theta0;          // current CFO and correction phase at frame start
-    int rerun;
+    int rerun, pad_;
     float sym_theta[64];        // correction phase at the first sample of each symbol
+    float sub_theta[16];        // ... and at every 72nd sample of the symbol being staged
+    float sums[8 * 64];         // ordered_sums scratch (16-byte aligned: see offset of this member)
 };
 
-__device__ inline void demod_fft_phase(const DemodArgs& A, const DemodConst& K, const float* __restrict__ x,
-                                       int n_sym, float2* tiles, float2* Y, DemodShared* sh, int lane, int wave) {
+// One step of the CFO correction phase (channel_equalizer.cpp:139-144): th += inc, wrapped with
+// double-precision pi.  For a float th, "th > M_PI" <=> th >= 0x40490fdb (the float just above pi),
+// so the common no-wrap step is one add and one compare; the wrap itself is done in double as written.
+__device__ __forceinline__ float cfo_phase_step(float th, float inc) {
+    th += inc;
+    const float kPiUp = u2f(0x40490fdbu);
+    if (fabs_(th) >= kPiUp) {
+        if (th > 0.0f) th = static_cast<float>(static_cast<double>(th) - 2.0f * 3.14159265358979323846);
+        else th = static_cast<float>(static_cast<double>(th) + 2.0f * 3.14159265358979323846);
+    }
+    return th;
+}
+
+// Eight steps at once: the wrap happens once per ~1000+ samples, so run the adds speculatively and
+// check the largest magnitude once; fall back to single steps only for the group that wraps.
+__device__ __forceinline__ float cfo_phase_step8(float th, float inc) {
+    const float kPiUp = u2f(0x40490fdbu);
+    float t1 = th + inc, t2 = t1 + inc, t3 = t2 + inc, t4 = t3 + inc;
+    float t5 = t4 + inc, t6 = t5 + inc, t7 = t6 + inc, t8 = t7 + inc;
+    float m = fmaxf(fmaxf(fmaxf(fabs_(t1), fabs_(t2)), fmaxf(fabs_(t3), fabs_(t4))),
+                    fmaxf(fmaxf(fabs_(t5), fabs_(t6)), fmaxf(fabs_(t7), fabs_(t8))));
+    if (m >= kPiUp) {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) th = cfo_phase_step(th, inc);
+        return th;
+    }
+    return t8;
+}
+
+__device__ __forceinline__ void demod_fft_phase(const DemodArgs& A, const DemodConst& K, const float* __restrict__ x,
+                                       int n_sym, float2* buf, float2* Y, DemodShared* sh, int lane) {
     const float cfo = sh->cfo;
     const bool use_cfo = fabs_(cfo) > 0.01f;
     const float inc = static_cast<float>(-2.0f * 3.14159265358979323846 * static_cast<double>(cfo) / 48000.0);
-    if (use_cfo) {
-        // channel_equalizer.cpp:132-144: float phase recurrence over EVERY sample (CP included), wrapped
-        // with double-precision pi.  Serial by construction; one lane walks it and records the phase at
-        // each symbol start, then each wave re-walks its own symbol.
-        if (wave == 0 && lane == 0) {
-            float th = sh->theta0;
-            for (int s = 0; s < n_sym; ++s) {
-                sh->sym_theta[s] = th;
-                for (int i = 0; i < kSym; ++i) {
-                    th += inc;
-                    if (static_cast<double>(th) > 3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) - 2.0f * 3.14159265358979323846);
-                    else if (static_cast<double>(th) < -3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) + 2.0f * 3.14159265358979323846);
-                }
-            }
-            sh->sym_theta[n_sym] = th;
-        }
-        __syncthreads();
-    }
-    float2* buf = tiles + wave * kFftBufFloats2;
-    for (int s = wave; s < n_sym; s += 4) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    float th_walk = sh->theta0;   // lane 0: correction phase at the start of the next symbol
+    for (int s = 0; s < n_sym; ++s) {
         float th_reg[16];
         if (use_cfo) {
-            // lane 0 walks this symbol's 1152 phases into the (still free) tile, all lanes pick theirs up
+            // channel_equalizer.cpp:132-144: float phase recurrence over EVERY sample (CP included), wrapped
+            // with double-precision pi.  Inherently serial: lane 0 walks the symbol once, dropping a
+            // marker every 72 samples; 16 lanes then re-walk 72 samples each into the (still free) tile.
             float* thb = reinterpret_cast<float*>(buf);
             if (lane == 0) {
-                float th = sh->sym_theta[s];
-                for (int i = 0; i < kSym; ++i) {
-                    thb[i] = th;
-                    th += inc;
-                    if (static_cast<double>(th) > 3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) - 2.0f * 3.14159265358979323846);
-                    else if (static_cast<double>(th) < -3.14159265358979323846) th = static_cast<float>(static_cast<double>(th) + 2.0f * 3.14159265358979323846);
+                float th = th_walk;
+                for (int q = 0; q < 16; ++q) {
+                    sh->sub_theta[q] = th;
+#pragma unroll 1
+                    for (int g = 0; g < 9; ++g) th = cfo_phase_step8(th, inc);
                 }
+                th_walk = th;
+            }
+            wave_sync();
+            if (lane < 16) {
+                float th = sh->sub_theta[lane];
+                for (int i = 0; i < 72; ++i) { thb[72 * lane + i] = th; th = cfo_phase_step(th, inc); }
             }
             wave_sync();
 #pragma unroll
@@ -394,12 +437,14 @@ __device__ inline void demod_fft_phase(const DemodArgs& A, const DemodConst& K, 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             int j = 4 * lane + 256 * c;
-            float4 v = *reinterpret_cast<const float4*>(xs + j);
-            float xv[4] = {v.x, v.y, v.z, v.w};
+            float xv[4];
+            if (aligned) { float4 v = *reinterpret_cast<const float4*>(xs + j); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+            else { xv[0] = xs[j]; xv[1] = xs[j + 1]; xv[2] = xs[j + 2]; xv[3] = xs[j + 3]; }
+            const float4 o01 = *reinterpret_cast<const float4*>(osc + j), o23 = *reinterpret_cast<const float4*>(osc + j + 2);
+            const float2 ov[4] = {make_float2(o01.x, o01.y), make_float2(o01.z, o01.w), make_float2(o23.x, o23.y), make_float2(o23.z, o23.w)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float2 o = osc[j + e];
-                float2 m = make_float2(xv[e] * o.x, xv[e] * -o.y);  // samples[i] * conj(osc)
+                float2 m = make_float2(xv[e] * ov[e].x, xv[e] * -ov[e].y);  // samples[i] * conj(osc)
                 if (use_cfo) m = cmul(m, cexpj(th_reg[4 * c + e]));
                 buf[j + e] = m;
             }
@@ -407,19 +452,19 @@ __device__ inline void demod_fft_phase(const DemodArgs& A, const DemodConst& K, 
         wave_sync();
         fft1024_wave(buf, A.twiddle, Y + s * 64, lane);
     }
-    __syncthreads();
+    if (lane == 0) sh->sym_theta[n_sym] = th_walk;
+    wave_sync();
 }
 
 __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DemodConst& K = *A.k;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     const int frame = blockIdx.x;
     const int n_sym = 2 + K.n_data_symbols;
-    float2* tiles = reinterpret_cast<float2*>(smem);                       // 4 * 1088 float2
-    float2* Y = tiles + 4 * kFftBufFloats2;                                // [n_sym][64]
+    float2* tiles = reinterpret_cast<float2*>(smem);                       // 1088 float2
+    float2* Y = tiles + kFftBufFloats2;                                    // [n_sym][64]
     DemodShared* sh = reinterpret_cast<DemodShared*>(Y + static_cast<size_t>(n_sym) * 64);
-    float* llr_lds = reinterpret_cast<float*>(tiles + kFftBufFloats2);     // aliases tiles 1..3 in phase E
 
     const float* x = A.samples + (A.offsets ? A.offsets[frame] : static_cast<uint64_t>(frame) * n_sym * kSym);
     if (threadIdx.x == 0) {
@@ -441,12 +486,12 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
         sh->theta0 = static_cast<float>(init);
         sh->rerun = 0;
     }
-    __syncthreads();
+    wave_sync();
     const bool negate_lts0 = A.meta && (A.meta[frame].flags & 1u);
 
-    // ================= phase F: all symbols through the FFT with the CFO the host supplied
-    demod_fft_phase(A, K, x, n_sym, tiles, Y, sh, lane, wave);
-
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (A.dbg) t0 = __builtin_readcyclecounter();
+    t1 = t0;
     // per-lane estimator state (wave 0; lane = logical carrier)
     float2 H = make_float2(1.0f, 0.0f);
     float noise_var = 0.1f, snr_lin = 1.0f, fading = 0.0f, slope = 0.0f;
@@ -454,14 +499,19 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
     const bool is_car = lane < kCarriers;
     const bool is_pil = is_car && K.is_pilot[lane];
     const bool is_dat = is_car && !K.is_pilot[lane];
-    const unsigned long long dmask = K.data_mask, pmask = K.pilot_mask;
+    const int my_ord = K.ord[lane];          // data ordinal (data carriers) / pilot ordinal (pilots)
+    float* T = sh->sums;
     const float2 txv = make_float2(K.tx_re[lane], K.tx_im[lane]);
     const float lsign = negate_lts0 ? -1.0f : 1.0f;
     float2 H0 = make_float2(0, 0), H1 = make_float2(0, 0);
 
     // ================= LTS channel estimate (channel_equalizer.cpp:193-643), possibly twice
     for (int pass = 0; pass < 2; ++pass) {
-        if (wave == 0) {
+        // ---- phase F: all symbols through the FFT with the current CFO (pass 1: mixer.reset(), phase
+        // restored to its value at training start, corrected CFO: channel_equalizer.cpp:337-344)
+        demod_fft_phase(A, K, x, n_sym, tiles, Y, sh, lane);
+        if (A.dbg && pass == 0) t1 = __builtin_readcyclecounter();
+        {
             float2 y0 = Y[0 * 64 + lane], y1 = Y[1 * 64 + lane];
             y0 = make_float2(lsign * y0.x, lsign * y0.y);  // burst marker: first LTS was negated on air
             if (is_car) { H0 = cdivc(y0, txv); H1 = cdivc(y1, txv); }
@@ -472,7 +522,9 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 float mag = cabs_(diff);
                 v = v && mag > 1e-6f;
                 float tr = v ? fdiv(diff.x, mag) : 0.0f, ti = v ? fdiv(diff.y, mag) : 0.0f;
-                float sr = ordered_sum(tr, dmask), si = ordered_sum(ti, dmask);
+                float o2[2];
+                { const float t2[2] = {tr, ti}; ordered_sums<2, 60>(t2, is_dat, my_ord, K.n_data, T, lane, o2); }
+                const float sr = o2[0], si = o2[1];
                 int cnt = __popcll(__ballot(v));
                 if (cnt > 10) {
                     float avg = atan2f_glibc(si, sr);
@@ -486,16 +538,11 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             }
             (void)rerun;
         }
-        __syncthreads();
-        if (pass == 0 && sh->rerun) {
-            // mixer.reset(), phase restored to its value at training start, corrected CFO: redo all symbols
-            demod_fft_phase(A, K, x, n_sym, tiles, Y, sh, lane, wave);
-        } else {
-            break;
-        }
+        wave_sync();
+        if (!(pass == 0 && sh->rerun)) break;
     }
 
-    if (wave != 0) goto write_out;
+    if (A.dbg) t2 = __builtin_readcyclecounter();
     {
         // H := last LTS symbol
         H = is_car ? H1 : make_float2(1.0f, 0.0f);
@@ -506,8 +553,9 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             float mag = cabs_(diff);
             v = v && mag > 1e-6f;
             float tr = v ? fdiv(diff.x, mag) : 0.0f, ti = v ? fdiv(diff.y, mag) : 0.0f;
-            unsigned long long m58 = (1ull << (kCarriers - 1)) - 1ull;
-            float sr = ordered_sum(tr, m58), si = ordered_sum(ti, m58);
+            float o2[2];
+            { const float t2[2] = {tr, ti}; ordered_sums<2, 60>(t2, lane < kCarriers - 1, lane, kCarriers - 1, T, lane, o2); }
+            const float sr = o2[0], si = o2[1];
             int cnt = __popcll(__ballot(v));
             if (cnt > 0) slope = atan2f_glibc(fdiv(si, static_cast<float>(cnt)), fdiv(sr, static_cast<float>(cnt)));
         }
@@ -516,7 +564,9 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             float2 d = make_float2(H1.x - H0.x, H1.y - H0.y);
             float tn = v ? cnorm(d) : 0.0f;
             float ts = v ? fdiv(cnorm(H0) + cnorm(H1), 2.0f) : 0.0f;
-            float ns = ordered_sum(tn, dmask), ss = ordered_sum(ts, dmask);
+            float o2[2];
+            { const float t2[2] = {tn, ts}; ordered_sums<2, 60>(t2, is_dat, my_ord, K.n_data, T, lane, o2); }
+            const float ns = o2[0], ss = o2[1];
             int cnt = __popcll(__ballot(v));
             if (cnt > 0) {
                 float nv = fdiv(ns, 4.0f * static_cast<float>(cnt));
@@ -529,9 +579,12 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
         }
         {   // fading index of |H| over data carriers
             float a = is_dat ? cabs_(H) : 0.0f;
-            float mean = fdiv(ordered_sum(a, dmask), static_cast<float>(K.n_data));
+            float o1[1];
+            { const float t1[1] = {a}; ordered_sums<1, 60>(t1, is_dat, my_ord, K.n_data, T, lane, o1); }
+            float mean = fdiv(o1[0], static_cast<float>(K.n_data));
             float dd_ = a - mean;
-            float var = fdiv(ordered_sum(is_dat ? dd_ * dd_ : 0.0f, dmask), static_cast<float>(K.n_data));
+            { const float t1[1] = {dd_ * dd_}; ordered_sums<1, 60>(t1, is_dat, my_ord, K.n_data, T, lane, o1); }
+            float var = fdiv(o1[0], static_cast<float>(K.n_data));
             fading = (mean > 0.01f) ? fdiv(fsqrt(var), mean) : 0.0f;
         }
         snr_count = 2;
@@ -548,6 +601,11 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
         const float ia = K.alpha[lane];
         const float npf = static_cast<float>(K.n_pilot), ndf = static_cast<float>(K.n_data);
 
+        // the LTS phase slope is fixed for the frame: de-slope / re-slope rotations once per lane
+        const float ph_des = -slope * static_cast<float>(kk), ph_res = slope * static_cast<float>(kk);
+        const float2 rot_des = make_float2(cosf_glibc(ph_des), sinf_glibc(ph_des));
+        const float2 rot_res = make_float2(cosf_glibc(ph_res), sinf_glibc(ph_res));
+
         for (int ds = 0; ds < K.n_data_symbols; ++ds) {
             float2 y = Y[(2 + ds) * 64 + lane];
             const bool first = (ds == 0);
@@ -558,29 +616,38 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 if (coh) {
                     cp_init = true;
                 } else if (!cp_init) {
-                    float2 hsum = make_float2(ordered_sum(hls.x, pmask), ordered_sum(hls.y, pmask));
+                    float o2[2];
+                    { const float t2[2] = {hls.x, hls.y}; ordered_sums<2, 16>(t2, is_pil, my_ord, K.n_pilot, T, lane, o2); }
+                    float2 hsum = make_float2(o2[0], o2[1]);
                     float2 havg = make_float2(fdiv(hsum.x, npf), fdiv(hsum.y, npf));
                     float am = cabs_(havg);
                     if (am > 0.01f) { cp_corr = make_float2(fdiv(havg.x, am), fdiv(-havg.y, am)); cp_init = true; }
                 }
                 hls = cmul(hls, cp_corr);
+                // All pilot-ordered sums of this symbol in one go (CPE numerator/denominator, signal power,
+                // temporal noise power, mean pilot magnitude): they only depend on hls, H and prev_pilot.
+                const float hls_abs = cabs_(hls);
+                float hm = cabs_(H);
+                float2 ratio = cmul(hls, conj_(H));
+                float mag = cabs_(ratio);
+                bool v = coh && is_pil && hm > 0.01f && mag > 1e-6f;
+                bool nvv = is_pil && have_prev && cnorm(prev_pilot) > 1e-6f && cnorm(hls) > 1e-6f;
+                float2 dp = make_float2(hls.x - prev_pilot.x, hls.y - prev_pilot.y);
+                float o6[6];
+                {
+                    const float t6[6] = {v ? fdiv(ratio.x, mag) * hm : 0.0f, v ? fdiv(ratio.y, mag) * hm : 0.0f,
+                                         v ? hm : 0.0f, cnorm(hls), nvv ? cnorm(dp) : 0.0f, hls_abs};
+                    ordered_sums<6, 16>(t6, is_pil, my_ord, K.n_pilot, T, lane, o6);
+                }
                 if (coh) {  // common phase error
-                    float hm = cabs_(H);
-                    float2 ratio = cmul(hls, conj_(H));
-                    float mag = cabs_(ratio);
-                    bool v = is_pil && hm > 0.01f && mag > 1e-6f;
-                    float tr = v ? fdiv(ratio.x, mag) * hm : 0.0f, ti = v ? fdiv(ratio.y, mag) * hm : 0.0f;
-                    float tw_ = v ? hm : 0.0f;
-                    float cr = ordered_sum(tr, pmask), ci = ordered_sum(ti, pmask), ws = ordered_sum(tw_, pmask);
+                    const float cr = o6[0], ci = o6[1], ws = o6[2];
                     if (ws > 0.01f) {
                         float ph = atan2f_glibc(ci, cr);
                         if (fabs_(ph) > 0.001f) H = cmul(H, cexpj(ph));
                     }
                 }
-                float signal_power = fdiv(ordered_sum(is_pil ? cnorm(hls) : 0.0f, pmask), npf);
-                bool nvv = is_pil && have_prev && cnorm(prev_pilot) > 1e-6f && cnorm(hls) > 1e-6f;
-                float2 dp = make_float2(hls.x - prev_pilot.x, hls.y - prev_pilot.y);
-                float noise_power_sum = ordered_sum(nvv ? cnorm(dp) : 0.0f, pmask);
+                float signal_power = fdiv(o6[3], npf);
+                float noise_power_sum = o6[4];
                 int noise_count = __popcll(__ballot(nvv));
                 if (is_pil) {
                     if (coh) {
@@ -596,8 +663,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 have_prev = true;
                 // interpolation between pilots
                 if (coh) {
-                    float ph = -slope * static_cast<float>(kk);
-                    float2 des = cmul(H, make_float2(cosf_glibc(ph), sinf_glibc(ph)));
+                    float2 des = cmul(H, rot_des);
                     float2 hl = make_float2(lane_read(des.x, lo < 0 ? 0 : lo), lane_read(des.y, lo < 0 ? 0 : lo));
                     float2 hu = make_float2(lane_read(des.x, hi < 0 ? 0 : hi), lane_read(des.y, hi < 0 ? 0 : hi));
                     if (is_dat) {
@@ -606,8 +672,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                             ih = make_float2((1.0f - ia) * hl.x + ia * hu.x, (1.0f - ia) * hl.y + ia * hu.y);
                         else if (lo >= 0) ih = hl;
                         else ih = hu;
-                        float p2 = slope * static_cast<float>(kk);
-                        H = cmul(ih, make_float2(cosf_glibc(p2), sinf_glibc(p2)));
+                        H = cmul(ih, rot_res);
                     }
                 } else {
                     float am = cabs_(H);
@@ -625,10 +690,11 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                     if (fabs_(dd) > 0.001f) H = cmul(H, cexpj(dd * 0.3f));
                 }
                 {   // fading index from pilot magnitudes
-                    float a = is_pil ? cabs_(hls) : 0.0f;
-                    float mean = fdiv(ordered_sum(a, pmask), npf);
-                    float df = a - mean;
-                    float vv = fdiv(ordered_sum(is_pil ? df * df : 0.0f, pmask), npf);
+                    float mean = fdiv(o6[5], npf);
+                    float df = hls_abs - mean;
+                    float o1[1];
+                    { const float t1[1] = {df * df}; ordered_sums<1, 16>(t1, is_pil, my_ord, K.n_pilot, T, lane, o1); }
+                    float vv = fdiv(o1[0], npf);
                     fading = (mean > 0.01f) ? fdiv(fsqrt(vv), mean) : 0.0f;
                 }
                 if (noise_count > 0 && noise_power_sum > 0.0f && coh && noise_count > 1) {
@@ -642,7 +708,9 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             float2 eq = make_float2(0, 0);
             {
                 float hp = cnorm(H);
-                float avg = fdiv(ordered_sum(is_dat ? hp : 0.0f, dmask), ndf);
+                float o1[1];
+                { const float t1[1] = {hp}; ordered_sums<1, 60>(t1, is_dat, my_ord, K.n_data, T, lane, o1); }
+                float avg = fdiv(o1[0], ndf);
                 float thr = 0.25f * avg;
                 if (!coh) {
                     float snv = noise_var;
@@ -699,7 +767,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 int nb = demap_symbol(mod, eq, dprev, nv, o);
                 if (!coh) dprev = eq;
                 if (is_dat) {
-                    float* dst = llr_lds + ds * K.bits_per_symbol + K.ord[lane] * K.bits_per_carrier;
+                    float* dst = A.llr_out + static_cast<size_t>(frame) * A.llr_stride + ds * K.bits_per_symbol + K.ord[lane] * K.bits_per_carrier;
                     for (int b = 0; b < nb; ++b) dst[b] = o[b];
                 }
             }
@@ -719,16 +787,14 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             A.status[frame] = st;
         }
     }
-write_out:
-    __syncthreads();
-    {
-        float* dst = A.llr_out + static_cast<size_t>(frame) * A.llr_stride;
-        for (int i = threadIdx.x; i < K.n_llr; i += kDemodThreads) dst[i] = llr_lds[i];
+    if (A.dbg && threadIdx.x == 0) {
+        t3 = __builtin_readcyclecounter();
+        A.dbg[frame * 4 + 0] = t1 - t0; A.dbg[frame * 4 + 1] = t2 - t1; A.dbg[frame * 4 + 2] = t3 - t2; A.dbg[frame * 4 + 3] = t3 - t0;
     }
 }
 
 inline int demod_lds_bytes(int n_sym) {
-    return 4 * kFftBufFloats2 * 8 + n_sym * 64 * 8 + static_cast<int>(sizeof(DemodShared)) + 16;
+    return kFftBufFloats2 * 8 + n_sym * 64 * 8 + static_cast<int>(sizeof(DemodShared)) + 16;
 }
 inline hipError_t demod_set_attributes() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(demod_frames_kernel),

@@ -541,6 +541,8 @@ int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64
     A.llr_out = llr_out_dev;
     A.llr_stride = h->geo.llrs_per_frame;
     A.status = status_dev;
+    A.dbg = nullptr;
+    if (const char* e = getenv("RIA_DEBUG_DEMOD_STAMPS")) A.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
     launch_demod(A, h->geo, static_cast<hipStream_t>(stream));
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
