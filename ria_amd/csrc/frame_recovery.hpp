@@ -7,6 +7,7 @@
 // Product code, independent of oracle/.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -56,6 +57,7 @@ struct Crc16Tables {
 struct FrameRecovery {
     const Crc16Tables& T;
     int bpc;  // info bytes per codeword
+    std::atomic<int>* stat_max_suspects = nullptr; std::atomic<long>* stat_sum_suspects = nullptr; std::atomic<long>* stat_cnt_suspects = nullptr;
     explicit FrameRecovery(const Crc16Tables& t, int bytes_per_cw) : T(t), bpc(bytes_per_cw) {}
 
     bool parse_header(const uint8_t* d, int len, bool* ctl, int* plen) const {  // frame_v2.cpp:1195-1252
@@ -221,6 +223,7 @@ struct FrameRecovery {
                                 int chb = l < 0, db = (cw[c][i / 8] >> (i % 8)) & 1;
                                 if (chb != db) sus.push_back({fbit, std::fabs(l)});
                             }
+                        if (stat_max_suspects) { int n_ = static_cast<int>(sus.size()); int o_ = stat_max_suspects->load(); while (n_ > o_ && !stat_max_suspects->compare_exchange_weak(o_, n_)) {} stat_sum_suspects->fetch_add(n_); stat_cnt_suspects->fetch_add(1); }
                         sort_suspects(sus);
                         int ns = std::min<int>(30, static_cast<int>(sus.size()));
                         uint16_t sd[30];

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,6 +51,13 @@ struct ria_gpu {
     CwResult* d_res = nullptr;            // [4 * ws_frames]
     uint8_t* d_res_bytes = nullptr;       // [4 * ws_frames][5][bytes_per_cw]
     int ws_frames = 0;
+    // CRC-recovery staging (device + pinned host mirrors), sized for ws_frames
+    unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr;
+    uint8_t* d_info_c = nullptr; float* d_rows_c = nullptr; uint8_t* d_redec_ok = nullptr; uint8_t* d_redec_bytes = nullptr;
+    ria_decode_status* d_st_c = nullptr;
+    unsigned int* p_rctl = nullptr; unsigned int* p_flagged = nullptr; uint8_t* p_info_c = nullptr; float* p_rows_c = nullptr;
+    uint8_t* p_redec_ok = nullptr; uint8_t* p_redec_bytes = nullptr; ria_decode_status* p_st_c = nullptr;
+    int rec_frames = 0;
     Crc16Tables crc;
 };
 
@@ -141,34 +149,6 @@ static void set_fast_attributes(int rate, int m, int k) {
 }
 
 // ---- CRC-guided false-positive recovery glue (host logic in frame_recovery.hpp) -----------------
-__global__ void gather_rows_kernel(const float* __restrict__ llr, int stride, const int* __restrict__ frame_idx,
-                                   const uint16_t* __restrict__ gather, float* __restrict__ rows) {
-    int f = blockIdx.x >> 2, cw = blockIdx.x & 3;
-    const float* src = llr + static_cast<size_t>(frame_idx[f]) * stride;
-    for (int i = threadIdx.x; i < 648; i += blockDim.x)
-        rows[static_cast<size_t>(blockIdx.x) * 648 + i] = src[gather[cw * 648 + i]];
-}
-__global__ void scatter_results_kernel(const int* __restrict__ frame_idx, const uint8_t* __restrict__ info_c,
-                                       const ria_decode_status* __restrict__ st_c, int info_bytes,
-                                       uint8_t* __restrict__ info_out, ria_decode_status* __restrict__ st_out) {
-    int f = blockIdx.x, dst = frame_idx[f];
-    for (int i = threadIdx.x; i < info_bytes; i += blockDim.x)
-        info_out[static_cast<size_t>(dst) * info_bytes + i] = info_c[static_cast<size_t>(f) * info_bytes + i];
-    if (threadIdx.x == 0) st_out[dst] = st_c[f];
-}
-
-__global__ void gather_info_kernel(const int* __restrict__ frame_idx, const uint8_t* __restrict__ info, int info_bytes,
-                                   uint8_t* __restrict__ info_c) {
-    int f = blockIdx.x;
-    for (int i = threadIdx.x; i < info_bytes; i += blockDim.x)
-        info_c[static_cast<size_t>(f) * info_bytes + i] = info[static_cast<size_t>(frame_idx[f]) * info_bytes + i];
-}
-__global__ void gather_rows_subset_kernel(const float* __restrict__ rows, const int* __restrict__ sub, float* __restrict__ out) {
-    // sub[b >> 2] = index of a flagged frame inside the compact rows array
-    size_t src = (static_cast<size_t>(sub[blockIdx.x >> 2]) * 4 + (blockIdx.x & 3)) * 648;
-    for (int i = threadIdx.x; i < 648; i += blockDim.x) out[static_cast<size_t>(blockIdx.x) * 648 + i] = rows[src + i];
-}
-
 template <class F>
 static void parallel_for(int n, F&& f) {
     int nt = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
@@ -180,106 +160,130 @@ static void parallel_for(int n, F&& f) {
     for (auto& t : th) t.join();
 }
 
-// Runs after the decode kernels when RIA_DECODE_CRC_RECOVER is set.  Synchronises the stream.
-// Stage 1 (CRC-guided searches) runs on the host threads for every flagged frame; only the frames
-// it cannot repair get the 16 re-decodes of stage 2, batched on the GPU.
-static int run_crc_recovery(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
-                            uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s) {
-    std::vector<ria_decode_status> st(n_frames);
-    HIP_TRY(h, hipMemcpyAsync(st.data(), status_dev, sizeof(ria_decode_status) * n_frames, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
-    std::vector<int> idx;
-    for (int f = 0; f < n_frames; ++f) if (st[f].needs_recovery) idx.push_back(f);
-    if (idx.empty()) return RIA_OK;
-    const int nf = static_cast<int>(idx.size()), bpc = h->geo.bytes_per_codeword, ib = h->geo.info_bytes_per_frame;
-    const int nb = (h->geo.info_bits + 7) / 8;
-    int* d_idx = nullptr; float* d_rows = nullptr; uint8_t* d_out = nullptr; uint8_t* d_ok = nullptr; uint16_t* d_it = nullptr;
-    uint8_t* d_info_c = nullptr; ria_decode_status* d_st_c = nullptr; int* d_sub = nullptr; float* d_rows2 = nullptr;
-    auto cleanup = [&]() { for (void* p_ : {(void*)d_idx, (void*)d_rows, (void*)d_out, (void*)d_ok, (void*)d_it, (void*)d_info_c, (void*)d_st_c, (void*)d_sub, (void*)d_rows2}) (void)hipFree(p_); };
-#define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    const int ncw = nf * 4;
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), nf * sizeof(int)));
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), static_cast<size_t>(ncw) * 648 * sizeof(float)));
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_info_c), static_cast<size_t>(nf) * ib));
-    R_TRY(hipMalloc(reinterpret_cast<void**>(&d_st_c), static_cast<size_t>(nf) * sizeof(ria_decode_status)));
-    R_TRY(hipMemcpyAsync(d_idx, idx.data(), nf * sizeof(int), hipMemcpyHostToDevice, s));
-    const uint16_t* gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(ncw), dim3(128), 0, s, llr_dev, llr_stride, d_idx, gather, d_rows);
-    hipLaunchKernelGGL(gather_info_kernel, dim3(nf), dim3(64), 0, s, d_idx, info_out_dev, ib, d_info_c);
+static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames) {
+    if (n_frames <= h->rec_frames) return hipSuccess;
+    for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_info_c, (void**)&h->d_rows_c,
+                     (void**)&h->d_redec_ok, (void**)&h->d_redec_bytes, (void**)&h->d_st_c}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {(void**)&h->p_rctl, (void**)&h->p_flagged, (void**)&h->p_info_c, (void**)&h->p_rows_c, (void**)&h->p_redec_ok,
+                     (void**)&h->p_redec_bytes, (void**)&h->p_st_c}) { if (*p) (void)hipHostFree(*p); *p = nullptr; }
+    const size_t n = static_cast<size_t>(n_frames), ib = h->geo.info_bytes_per_frame, bpc = h->geo.bytes_per_codeword;
+    hipError_t e;
+#define A_TRY(expr) if ((e = (expr)) != hipSuccess) return e
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_info_c), n * ib));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rows_c), n * 4 * 648 * 4));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_redec_ok), n * 16));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_redec_bytes), n * 16 * bpc));
+    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_st_c), n * sizeof(ria_decode_status)));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_rctl), 16, hipHostMallocDefault));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_flagged), n * 4, hipHostMallocDefault));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_info_c), n * ib, hipHostMallocDefault));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_rows_c), n * 4 * 648 * 4, hipHostMallocDefault));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_redec_ok), n * 16, hipHostMallocDefault));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_redec_bytes), n * 16 * bpc, hipHostMallocDefault));
+    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_st_c), n * sizeof(ria_decode_status), hipHostMallocDefault));
+#undef A_TRY
+    h->rec_frames = n_frames;
+    return hipSuccess;
+}
+
+__global__ void recovery_status_gather_kernel(const unsigned int* n_flagged, const unsigned int* flagged,
+                                              const ria_decode_status* st, ria_decode_status* st_c) {
+    unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < *n_flagged) st_c[q] = st[flagged[q]];
+}
+__global__ void recovery_scatter_kernel(int nf, const unsigned int* __restrict__ flagged, const uint8_t* __restrict__ info_c,
+                                        const ria_decode_status* __restrict__ st_c, int info_bytes,
+                                        uint8_t* __restrict__ info_out, ria_decode_status* __restrict__ st_out) {
+    int f = blockIdx.x;
+    if (f >= nf) return;
+    unsigned dst = flagged[f];
+    for (int i = threadIdx.x; i < info_bytes; i += blockDim.x)
+        info_out[static_cast<size_t>(dst) * info_bytes + i] = info_c[static_cast<size_t>(f) * info_bytes + i];
+    if (threadIdx.x == 0) st_out[dst] = st_c[f];
+}
+
+// Runs after the decode kernels when RIA_DECODE_CRC_RECOVER is set (frame_v2.cpp:1564-1880).
+// The GPU lists the flagged frames, completes the min-sum-factor result table for them (the fallback
+// stage re-decodes with 0.75/0.625/0.5/0.875: the same decodes phase 0 makes) and packs the host
+// stage's inputs into pinned buffers; the byte-level CRC searches run on the host threads.
+// Synchronises the stream.
+static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s) {
+    static const bool tdbg = getenv("RIA_DEBUG_RECOVERY") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int n_frames = D.n_frames;
+    double tA = now();
+    hipError_t e0 = ensure_recovery_ws(h, std::max(n_frames, h->cfg.max_batch));
+    if (e0 != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery workspace: %s", hipGetErrorString(e0));
+    const int bpc = h->geo.bytes_per_codeword, ib = h->geo.info_bytes_per_frame;
+    RecoveryArgs R;
+    R.d = D;
+    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1;
+    R.flagged = h->d_flagged; R.list2 = h->d_list2;
+    R.info_c = h->d_info_c; R.rows_c = h->d_rows_c; R.redec_ok = h->d_redec_ok; R.redec_bytes = h->d_redec_bytes;
+#define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+    R_TRY(hipMemsetAsync(h->d_rctl, 0, 16, s));
+    hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
+    const int wb = fast_wave_lds_bytes(h->fast.m, h->fast.k);
+    dispatch_shape(h->cfg.code_rate, [&](auto sh) {
+        using S = decltype(sh);
+        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(n_frames * 16), dim3(64), wb, s, R);
+    });
+    hipLaunchKernelGGL(recovery_gather_kernel, dim3(n_frames), dim3(256), 0, s, R);
+    hipLaunchKernelGGL(recovery_status_gather_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, h->d_rctl, h->d_flagged,
+                       D.status, h->d_st_c);
     R_TRY(hipGetLastError());
-    std::vector<float> rows(static_cast<size_t>(ncw) * 648);
-    std::vector<uint8_t> info_c(static_cast<size_t>(nf) * ib);
-    std::vector<ria_decode_status> st_c(nf);
-    R_TRY(hipMemcpyAsync(rows.data(), d_rows, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    R_TRY(hipMemcpyAsync(info_c.data(), d_info_c, info_c.size(), hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(h->p_rctl, h->d_rctl, 16, hipMemcpyDeviceToHost, s));
     R_TRY(hipStreamSynchronize(s));
+    double tB = now();
+    const int nf = static_cast<int>(h->p_rctl[0]);
+    if (nf == 0) return RIA_OK;
+    R_TRY(hipMemcpyAsync(h->p_flagged, h->d_flagged, static_cast<size_t>(nf) * 4, hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(h->p_info_c, h->d_info_c, static_cast<size_t>(nf) * ib, hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(h->p_rows_c, h->d_rows_c, static_cast<size_t>(nf) * 4 * 648 * 4, hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(h->p_redec_ok, h->d_redec_ok, static_cast<size_t>(nf) * 16, hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(h->p_redec_bytes, h->d_redec_bytes, static_cast<size_t>(nf) * 16 * bpc, hipMemcpyDeviceToHost, s));
+    R_TRY(hipMemcpyAsync(h->p_st_c, h->d_st_c, static_cast<size_t>(nf) * sizeof(ria_decode_status), hipMemcpyDeviceToHost, s));
+    R_TRY(hipStreamSynchronize(s));
+    double tC = now();
     FrameRecovery rec(h->crc, bpc);
-    std::vector<uint8_t> good(nf, 0);
-    auto load_cw = [&](int i, uint8_t cw[4][68]) {
-        std::memset(cw, 0, 4 * 68);
-        for (int c = 0; c < 4; ++c) std::memcpy(cw[c], info_c.data() + static_cast<size_t>(i) * ib + c * bpc, bpc);
-    };
-    auto store_cw = [&](int i, uint8_t cw[4][68]) {
-        for (int c = 0; c < 4; ++c) std::memcpy(info_c.data() + static_cast<size_t>(i) * ib + c * bpc, cw[c], bpc);
-    };
+    std::atomic<int> n_stage2{0};
     parallel_for(nf, [&](int i) {
         uint8_t cw[4][68];
-        load_cw(i, cw);
-        if (rec.recover_search(cw, rows.data() + static_cast<size_t>(i) * 4 * 648)) { good[i] = 1; store_cw(i, cw); }
-    });
-    std::vector<int> sub;
-    for (int i = 0; i < nf; ++i) if (!good[i]) sub.push_back(i);
-    if (!sub.empty()) {
-        const int ns = static_cast<int>(sub.size()), ncw2 = ns * 4;
-        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_sub), ns * sizeof(int)));
-        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows2), static_cast<size_t>(ncw2) * 648 * sizeof(float)));
-        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), static_cast<size_t>(4) * ncw2 * nb));
-        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_ok), static_cast<size_t>(4) * ncw2));
-        R_TRY(hipMalloc(reinterpret_cast<void**>(&d_it), static_cast<size_t>(4) * ncw2 * sizeof(uint16_t)));
-        R_TRY(hipMemcpyAsync(d_sub, sub.data(), ns * sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(gather_rows_subset_kernel, dim3(ncw2), dim3(128), 0, s, d_rows, d_sub, d_rows2);
-        static const float rf[4] = {0.75f, 0.625f, 0.5f, 0.875f};  // frame_v2.cpp:1837
-        for (int at = 0; at < 4; ++at)
-            dispatch_shape(h->cfg.code_rate, [&](auto sh) {
-                using S = decltype(sh);
-                hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(ncw2, 8192)), dim3(64), fast_wave_lds_bytes(h->fast.m, h->fast.k), s,
-                                   h->fast, d_rows2, ncw2, h->geo.ldpc_max_iterations, rf[at],
-                                   d_out + static_cast<size_t>(at) * ncw2 * nb, d_ok + static_cast<size_t>(at) * ncw2,
-                                   d_it + static_cast<size_t>(at) * ncw2);
-            });
-        R_TRY(hipGetLastError());
-        std::vector<uint8_t> out(static_cast<size_t>(4) * ncw2 * nb), ok(static_cast<size_t>(4) * ncw2);
-        R_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, s));
-        R_TRY(hipMemcpyAsync(ok.data(), d_ok, ok.size(), hipMemcpyDeviceToHost, s));
-        R_TRY(hipStreamSynchronize(s));
-        parallel_for(ns, [&](int q) {
-            int i = sub[q];
-            uint8_t cw[4][68], rd[4][4][68], rok[4][4];
-            load_cw(i, cw);
+        std::memset(cw, 0, sizeof(cw));
+        uint8_t* inf = h->p_info_c + static_cast<size_t>(i) * ib;
+        for (int c = 0; c < 4; ++c) std::memcpy(cw[c], inf + c * bpc, bpc);
+        bool good = rec.recover_search(cw, h->p_rows_c + static_cast<size_t>(i) * 4 * 648);
+        if (!good) {
+            n_stage2++;
+            uint8_t rd[4][4][68], rok[4][4];
             for (int at = 0; at < 4; ++at)
                 for (int c = 0; c < 4; ++c) {
-                    size_t r = static_cast<size_t>(at) * ncw2 + static_cast<size_t>(q) * 4 + c;
-                    rok[at][c] = ok[r];
-                    std::memcpy(rd[at][c], out.data() + r * nb, bpc);
+                    rok[at][c] = h->p_redec_ok[static_cast<size_t>(i) * 16 + at * 4 + c];
+                    std::memcpy(rd[at][c], h->p_redec_bytes + (static_cast<size_t>(i) * 16 + at * 4 + c) * bpc, bpc);
                 }
-            if (rec.recover_fallback(cw, rok, rd)) { good[i] = 1; store_cw(i, cw); }
-        });
-    }
-    for (int i = 0; i < nf; ++i) {
-        ria_decode_status sn = st[idx[i]];
+            good = rec.recover_fallback(cw, rok, rd);
+        }
+        ria_decode_status& sn = h->p_st_c[i];
         sn.needs_recovery = 0;
-        sn.frame_valid = good[i];
-        for (int c = 0; c < 4; ++c) sn.cw_ok[c] = good[i];
-        if (!good[i]) std::memset(info_c.data() + static_cast<size_t>(i) * ib, 0, ib);
-        st_c[i] = sn;
-    }
-    R_TRY(hipMemcpyAsync(d_info_c, info_c.data(), info_c.size(), hipMemcpyHostToDevice, s));
-    R_TRY(hipMemcpyAsync(d_st_c, st_c.data(), st_c.size() * sizeof(ria_decode_status), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(scatter_results_kernel, dim3(nf), dim3(64), 0, s, d_idx, d_info_c, d_st_c, ib, info_out_dev, status_dev);
+        sn.frame_valid = good ? 1 : 0;
+        for (int c = 0; c < 4; ++c) {
+            sn.cw_ok[c] = good ? 1 : 0;
+            if (good) std::memcpy(inf + c * bpc, cw[c], bpc); else std::memset(inf + c * bpc, 0, bpc);
+        }
+    });
+    double tD = now();
+    R_TRY(hipMemcpyAsync(h->d_info_c, h->p_info_c, static_cast<size_t>(nf) * ib, hipMemcpyHostToDevice, s));
+    R_TRY(hipMemcpyAsync(h->d_st_c, h->p_st_c, static_cast<size_t>(nf) * sizeof(ria_decode_status), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(recovery_scatter_kernel, dim3(nf), dim3(64), 0, s, nf, h->d_flagged, h->d_info_c, h->d_st_c, ib, D.info_out,
+                       D.status);
     R_TRY(hipGetLastError());
     R_TRY(hipStreamSynchronize(s));
 #undef R_TRY
-    cleanup();
+    if (tdbg) fprintf(stderr, "[ria_gpu] recovery: frames %d flagged %d stage2 %d | gpu(decode+prep) %.2f ms, D2H %.2f ms, host search %.2f ms, H2D+scatter %.2f ms\n",
+                      n_frames, nf, n_stage2.load(), tB - tA, tC - tB, tD - tC, now() - tD);
     return RIA_OK;
 }
 
@@ -311,6 +315,10 @@ void ria_gpu_destroy(ria_gpu_handle h) {
                     h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
                     h->d_f_perm, h->d_f_row_ne, h->d_f_row_var, h->d_f_col_deg, h->d_f_col_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_info_c, (void*)h->d_rows_c,
+                    (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
+                    (void*)h->p_redec_bytes, (void*)h->p_st_c}) if (p) (void)hipHostFree(p);
     delete h;
 }
 
@@ -458,6 +466,8 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     hipError_t e = ensure_decode_ws(h, n_frames);
     if (e != hipSuccess) return fail(h, RIA_ERR_HIP, "decode workspace: %s", hipGetErrorString(e));
     FastDecodeArgs A;
+    if ((e = hipMemsetAsync(h->d_res, 0, static_cast<size_t>(n_frames) * 4 * sizeof(CwResult), s)) != hipSuccess)
+        return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     A.c = h->fast;
     A.gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
     A.llr = llr_dev;
@@ -506,6 +516,8 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     hipLaunchKernelGGL(frame_validate_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, s, info_out_dev,
                        h->geo.bytes_per_codeword, n_frames, A.crc_bit, A.crc_init, status_dev);
     stage("validate");
+    if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "decode kernel launch failed");
+    if (flags & RIA_DECODE_CRC_RECOVER) return run_crc_recovery(h, A, s);
     return RIA_OK;
 }
 
@@ -515,11 +527,7 @@ int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     if (!h || !llr_dev || !info_out_dev || !status_dev || n_frames < 0 || llr_stride < kFrameBits)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_decode_batch: bad argument (llr_stride must be >= 2592)");
     HIP_TRY(h, hipSetDevice(h->device));
-    launch_decode(h, llr_dev, llr_stride, n_frames, flags, info_out_dev, status_dev, static_cast<hipStream_t>(stream));
-    HIP_TRY(h, hipGetLastError());
-    if (flags & RIA_DECODE_CRC_RECOVER)
-        return run_crc_recovery(h, llr_dev, llr_stride, n_frames, flags, info_out_dev, status_dev, static_cast<hipStream_t>(stream));
-    return RIA_OK;
+    return launch_decode(h, llr_dev, llr_stride, n_frames, flags, info_out_dev, status_dev, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ demod
@@ -567,15 +575,9 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
         int rc = ria_gpu_demod_batch(h, smp, offs, meta_dev ? meta_dev + done : nullptr, nb, llr,
                                      demod_status_dev ? demod_status_dev + done : nullptr, stream);
         if (rc != RIA_OK) return rc;
-        launch_decode(h, llr, h->geo.llrs_per_frame, nb, flags,
-                      info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame, decode_status_dev + done, s);
-        HIP_TRY(h, hipGetLastError());
-        if (flags & RIA_DECODE_CRC_RECOVER) {
-            rc = run_crc_recovery(h, llr, h->geo.llrs_per_frame, nb, flags,
-                                  info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame,
-                                  decode_status_dev + done, s);
-            if (rc != RIA_OK) return rc;
-        }
+        rc = launch_decode(h, llr, h->geo.llrs_per_frame, nb, flags,
+                           info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame, decode_status_dev + done, s);
+        if (rc != RIA_OK) return rc;
         done += nb;
     }
     return RIA_OK;
