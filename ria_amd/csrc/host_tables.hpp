@@ -212,53 +212,88 @@ inline LdpcCode build_ldpc(int rate) {  // ldpc_decoder.cpp:21-36, :65-138 (enco
     return c;
 }
 
-// ---------------------------------------------------------------- LDPC tables for the wave decoder
-// Rows are re-ordered by decreasing degree so that the 64 rows one wavefront processes together in a
-// "round" have (nearly) the same number of edges; position p = 64*round + lane handles check perm[p].
-// The arithmetic is unaffected: variable sums still run in ascending ORIGINAL check order.
-struct FastTables {
-    int k = 0, m = 0, n_rounds = 0, n_col_rounds = 0, max_col_deg = 0;
-    std::vector<uint16_t> perm;        // [m] position -> check index
-    std::vector<uint8_t> row_ne;       // [m] information edges of the check at position p
-    std::vector<uint16_t> row_var;     // [6][m] information variable of slot s at position p (0 if unused)
-    std::vector<uint8_t> col_deg;      // [k]
-    std::vector<uint16_t> col_slot;    // [max_col_deg][k] slot word index s*m + p, ascending check order
-    uint8_t round_ne[8] = {0};         // max information edges per row round (wave-uniform loop bounds)
-    uint8_t round_cd[16] = {0};        // max column degree per column round
+// ---------------------------------------------------------------- register-resident decoder tables
+// Layout the wave-per-codeword decoder (ldpc_fast.hip.h) works on.  Rows are sorted by decreasing number
+// of information edges and cut into rounds of 64 rows of EQUAL degree (a new round starts whenever the
+// degree changes, the tail lanes of a round stay idle); information columns are sorted by decreasing
+// degree, 64 per round.  The arithmetic is unaffected: variable sums still run in ascending ORIGINAL
+// check order.  All addresses are BYTE offsets inside the wave's LDS region:
+//   c2v word of (round r, slot s, lane l) = 64*(row_off[r] + s) + l
+//   total of the column at sorted position q = tot_word + q;  64 words of +0.0f at zero_word.
+struct CoreTables {
+    int k = 0, m = 0;
+    std::vector<int> ne;               // information edges per row round
+    std::vector<int> dv;               // max degree per column round
+    int ts = 0, td = 0, tot_word = 0, zero_word = 0;
+    std::vector<uint16_t> row_addr;    // [ts][64]
+    std::vector<uint16_t> col_addr;    // [td][64]
+    std::vector<uint16_t> check_at;    // [64*NR]  0xFFFF idle
+    std::vector<uint16_t> col_at;      // [64*NC]  0xFFFF idle
+    std::vector<uint16_t> col_pos;     // [k]
 };
 
-inline FastTables build_fast_tables(const LdpcCode& c) {
-    FastTables t;
+inline CoreTables build_core_tables(const LdpcCode& c) {
+    CoreTables t;
     t.k = c.k; t.m = c.m;
     const int k = c.k, m = c.m;
-    t.perm.resize(m);
-    for (int i = 0; i < m; ++i) t.perm[i] = static_cast<uint16_t>(i);
-    std::stable_sort(t.perm.begin(), t.perm.end(), [&](uint16_t a, uint16_t b) { return c.rows[a].size() > c.rows[b].size(); });
-    std::vector<int> pos(m);
-    for (int p = 0; p < m; ++p) pos[t.perm[p]] = p;
-    t.row_ne.assign(m, 0);
-    t.row_var.assign(static_cast<size_t>(6) * m, 0);
-    t.n_rounds = (m + 63) / 64;
-    for (int p = 0; p < m; ++p) {
-        const auto& row = c.rows[t.perm[p]];
-        int ne = static_cast<int>(row.size()) - 1;  // last edge is the identity column k+i
-        t.row_ne[p] = static_cast<uint8_t>(ne);
-        for (int s = 0; s < ne; ++s) t.row_var[static_cast<size_t>(s) * m + p] = static_cast<uint16_t>(row[s]);
-        t.round_ne[p / 64] = std::max<uint8_t>(t.round_ne[p / 64], static_cast<uint8_t>(ne));
+    auto info_deg = [&](int i) { return static_cast<int>(c.rows[i].size()) - 1; };  // last edge: identity column k+i
+    std::vector<uint16_t> rows(m);
+    for (int i = 0; i < m; ++i) rows[i] = static_cast<uint16_t>(i);
+    std::stable_sort(rows.begin(), rows.end(), [&](uint16_t a, uint16_t b) { return info_deg(a) > info_deg(b); });
+    std::vector<int> pos(m);   // check -> position 64*round + lane
+    for (int i = 0; i < m;) {
+        const int d = info_deg(rows[i]);
+        int j = i;
+        while (j < m && info_deg(rows[j]) == d) ++j;
+        for (int b = i; b < j; b += 64) {
+            const int r = static_cast<int>(t.ne.size());
+            t.ne.push_back(d);
+            t.check_at.resize(static_cast<size_t>(64) * (r + 1), 0xFFFF);
+            for (int l = 0; l < 64 && b + l < j; ++l) { t.check_at[64 * r + l] = rows[b + l]; pos[rows[b + l]] = 64 * r + l; }
+        }
+        i = j;
     }
+    const int NR = static_cast<int>(t.ne.size());
+    std::vector<int> row_off(NR + 1, 0);
+    for (int r = 0; r < NR; ++r) row_off[r + 1] = row_off[r] + t.ne[r];
+    t.ts = row_off[NR];
+    // columns: c2v word list in ascending original check order
     std::vector<std::vector<uint16_t>> cols(k);
-    for (int i = 0; i < m; ++i) {  // ascending original check index
+    for (int i = 0; i < m; ++i) {
         const auto& row = c.rows[i];
-        for (size_t s = 0; s + 1 < row.size(); ++s) cols[row[s]].push_back(static_cast<uint16_t>(s * m + pos[i]));
+        const int r = pos[i] / 64, l = pos[i] % 64;
+        for (size_t s = 0; s + 1 < row.size(); ++s) cols[row[s]].push_back(static_cast<uint16_t>(64 * (row_off[r] + static_cast<int>(s)) + l));
     }
-    for (auto& v : cols) t.max_col_deg = std::max(t.max_col_deg, static_cast<int>(v.size()));
-    t.col_deg.assign(k, 0);
-    t.col_slot.assign(static_cast<size_t>(std::max(1, t.max_col_deg)) * k, 0);
-    t.n_col_rounds = (k + 63) / 64;
-    for (int j = 0; j < k; ++j) {
-        t.col_deg[j] = static_cast<uint8_t>(cols[j].size());
-        t.round_cd[j / 64] = std::max<uint8_t>(t.round_cd[j / 64], t.col_deg[j]);
-        for (size_t d = 0; d < cols[j].size(); ++d) t.col_slot[d * k + j] = cols[j][d];
+    std::vector<uint16_t> order(k);
+    for (int j = 0; j < k; ++j) order[j] = static_cast<uint16_t>(j);
+    std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return cols[a].size() > cols[b].size(); });
+    const int NC = (k + 63) / 64;
+    t.col_at.assign(static_cast<size_t>(64) * NC, 0xFFFF);
+    t.col_pos.assign(k, 0);
+    t.dv.assign(NC, 0);
+    for (int q = 0; q < k; ++q) {
+        t.col_at[q] = order[q];
+        t.col_pos[order[q]] = static_cast<uint16_t>(q);
+        t.dv[q / 64] = std::max(t.dv[q / 64], static_cast<int>(cols[order[q]].size()));
+    }
+    std::vector<int> col_off(NC + 1, 0);
+    for (int r = 0; r < NC; ++r) col_off[r + 1] = col_off[r] + t.dv[r];
+    t.td = col_off[NC];
+    t.tot_word = 64 * t.ts;
+    t.zero_word = t.tot_word + 64 * NC;
+    const uint16_t zero_addr = static_cast<uint16_t>(4 * t.zero_word);
+    t.row_addr.assign(static_cast<size_t>(64) * std::max(1, t.ts), zero_addr);
+    for (int r = 0; r < NR; ++r)
+        for (int l = 0; l < 64; ++l) {
+            const uint16_t i = t.check_at[64 * r + l];
+            if (i == 0xFFFF) continue;
+            for (int s = 0; s < t.ne[r]; ++s)
+                t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l] = static_cast<uint16_t>(4 * (t.tot_word + t.col_pos[c.rows[i][s]]));
+        }
+    t.col_addr.assign(static_cast<size_t>(64) * std::max(1, t.td), zero_addr);
+    for (int q = 0; q < k; ++q) {
+        const auto& v = cols[order[q]];
+        for (size_t d = 0; d < v.size(); ++d) t.col_addr[static_cast<size_t>(64) * (col_off[q / 64] + static_cast<int>(d)) + q % 64] = static_cast<uint16_t>(4 * v[d]);
     }
     return t;
 }

@@ -1,21 +1,29 @@
-// ria_amd/csrc/ldpc_fast.hip.h — register-resident flooding min-sum LDPC(648,k) decoder, v2.
+// ria_amd/csrc/ldpc_fast.hip.h — register-resident flooding min-sum LDPC(648,k) decoder, core v5.
 //
-// Same arithmetic as ldpc_kernels.hip.h (bit-exact LDPCDecoder::decodeBP, ldpc_decoder.cpp:154-260);
-// what changes is where things live and how work is scheduled:
-//   * one wavefront per codeword, NO index loads in the iteration loop: each lane owns rows
-//     i = lane + 64r and information columns j = lane + 64r; their degrees and message-slot addresses
-//     sit in VGPRs (packed u16), loaded once per decode;
+// Arithmetic: bit-exact LDPCDecoder::decodeBP (ldpc_decoder.cpp:154-260) for finite LLRs (|x| <= 1e30,
+// see include/ria_gpu.h).  What is MI355X-specific is where things live and how work is scheduled:
+//   * one wavefront per codeword, NO index loads and NO per-edge predication in the iteration loop.
+//     Rows are grouped by degree into "rounds" of 64 rows with the SAME number of information edges
+//     (the round structure of each code is a compile-time shape, checked against the generated H at
+//     create time), so the unrolled loop body contains exactly the edges that exist;
+//   * every LDS address is either lane*4 + immediate (the row's own c2v words, the column totals) or one
+//     VGPR loaded once per decode (the gather addresses);
 //   * the identity (parity) column k+i has a single edge, to row i, owned by the SAME lane: its
 //     message never touches LDS and its variable update is fused into the check pass;
-//   * the syndrome of iteration t is evaluated inside the check pass of iteration t+1 from per-edge
-//     hard-bit bytes the variable pass leaves next to the messages (no adjacency walk);
-//   * LDS per wave: [6][m] floats + [6][m] bytes (9.7 KB at R1/2), so >= 12 waves per CU;
+//   * the syndrome of iteration t is evaluated inside the check pass of iteration t+1 from the sign
+//     bits of the column totals it reads anyway;
+//   * information columns are ordered by degree too; a padded column slot reads a word that holds
+//     +0.0f (x + 0.0f == x), idle lanes own private padding words, so nothing is masked;
+//   * sign/magnitude work is integer work on the float bit patterns: zeros are kept canonical (+0.0)
+//     so that "x < 0" IS the sign bit, |x| orders like the unsigned pattern, min1/min2 are
+//     v_min_u32 / v_med3_u32, the clamp is one v_med3_f32;
 //   * the retry cascade (frame_v2.cpp:1415-1546) is a second, persistent kernel over a device-side
-//     work list of (codeword, attempt) units, so one hopeless codeword no longer pins a whole
-//     workgroup for 39 x 80 iterations while its three sibling waves idle.
+//     work list of (codeword, attempt) units.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/ria_gpu.h"
 #include "devmath.h"
@@ -23,255 +31,250 @@
 
 namespace ria {
 
-constexpr int kInfoSlots = 6;  // information edges per check (max_check_degree, ldpc_decoder.cpp:87)
-
-// Compile-time shape of a code: RR row rounds (ceil(m/64)), IR information-column rounds (ceil(k/64)),
-// DV max information-column degree.
-template <int RR_, int IR_, int DV_>
-struct CodeShape { static constexpr int RR = RR_, IR = IR_, DV = DV_; };
-using ShapeR12 = CodeShape<6, 6, 5>;    // R1/2: m = 324, k = 324, dv <= 5
-using ShapeR13 = CodeShape<6, 6, 6>;    // R1/3 (same k, m; H seeded differently): dv <= 6
-using ShapeR14 = CodeShape<8, 3, 13>;   // m = 486, k = 162
-using ShapeR23 = CodeShape<4, 7, 3>;    // m = 216, k = 432
-using ShapeR34 = CodeShape<3, 8, 3>;    // m = 162, k = 486
-using ShapeR56 = CodeShape<2, 9, 3>;    // m = 108, k = 540
-
-// Device view of host_tables.hpp FastTables (rows sorted by degree: position p = 64*round + lane).
-struct FastCode {
-    int k, m, max_iter, bytes_per_cw;
-    const uint16_t* perm;      // [m] position -> check index
-    const uint8_t* row_ne;     // [m] information edges at position p
-    const uint16_t* row_var;   // [6][m] information variable of slot s at position p
-    const uint8_t* col_deg;    // [k]
-    const uint16_t* col_slot;  // [dv][k] slot word index s*m + p, ascending check order
-    uint8_t round_ne[8];       // wave-uniform loop bounds
-    uint8_t round_cd[16];
+// ---- compile-time shape of a code ------------------------------------------------------------------
+// NR row rounds with ne(r) information edges each (rows sorted by decreasing degree, a new round starts
+// whenever the degree changes), NC information-column rounds with dv(r) = largest degree in the round
+// (columns sorted by decreasing degree).  host_tables.hpp derives the same structure from H and
+// ria_gpu_create refuses a code whose structure differs.
+struct ShapeR12 {   // R1/2: m = 324, k = 324
+    static constexpr int NR = 7, NC = 6;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 2, 1}; return t[r]; }
+    static constexpr int dv(int r) { constexpr int t[NC] = {5, 4, 4, 4, 4, 4}; return t[r]; }
+};
+struct ShapeR13 {   // R1/3 entry of the rate table: same (324,324) parameters, H seeded differently
+    static constexpr int NR = 8, NC = 6;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 3, 2, 1}; return t[r]; }
+    static constexpr int dv(int r) { constexpr int t[NC] = {6, 4, 4, 4, 4, 4}; return t[r]; }
+};
+struct ShapeR14 {   // m = 486, k = 162
+    static constexpr int NR = 11, NC = 3;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1}; return t[r]; }
+    static constexpr int dv(int r) { constexpr int t[NC] = {13, 12, 12}; return t[r]; }
+};
+struct ShapeR23 {   // m = 216, k = 432
+    static constexpr int NR = 5, NC = 7;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6, 6, 4}; return t[r]; }
+    static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 3}; return t[r]; }
+};
+struct ShapeR34 {   // m = 162, k = 486 (161 information columns have no edge at all)
+    static constexpr int NR = 3, NC = 8;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
+    static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 0, 0}; return t[r]; }
+};
+struct ShapeR56 {   // m = 108, k = 540
+    static constexpr int NR = 2, NC = 9;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
+    static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 0, 0, 0, 0, 0}; return t[r]; }
 };
 
-// LDS per wave (words): c2v messages [6][m] | total LLR of the information columns [k] | 64 dummy words
-// (stores of inactive edges are redirected there, one word per lane, to keep the loop branch-free).
-// The same region doubles as mt19937 state + 648 normals during the retry cascade (>= 1296 words).
-__host__ __device__ inline int fast_tot_word(int m) { return kInfoSlots * m; }
-__host__ __device__ inline int fast_dummy_word(int m, int k) { return kInfoSlots * m + k; }
-__host__ __device__ inline int fast_wave_lds_bytes(int m, int k = 324) {
-    int w = kInfoSlots * m + k + 64;
-    if (w < 1296) w = 1296;
-    return (w * 4 + 15) & ~15;
+template <class S>
+struct ShapeInfo {
+    static constexpr int row_off(int r) { int t = 0; for (int i = 0; i < r; ++i) t += S::ne(i); return t; }   // x 64 words
+    static constexpr int col_off(int r) { int t = 0; for (int i = 0; i < r; ++i) t += S::dv(i); return t; }
+    static constexpr int TS = row_off(S::NR);          // c2v slot groups (64 words each)
+    static constexpr int TD = col_off(S::NC);          // column gather addresses per lane
+    static constexpr int tot_word = 64 * TS;           // column totals [64*NC]
+    static constexpr int zero_word = tot_word + 64 * S::NC;   // 64 words of +0.0f
+    static constexpr int words = zero_word + 64;
+    // the same region doubles as mt19937 state + 648 normals during the retry cascade (>= 1296 words)
+    static constexpr int lds_bytes = ((words < 1296 ? 1296 : words) * 4 + 15) & ~15;
+};
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
+
+// Device view of host_tables.hpp CoreTables.
+struct FastCode {
+    int k, m, max_iter, bytes_per_cw;
+    const uint16_t* row_addr;   // [TS][64]  byte address of tot[column] read by (slot group, lane); zero word when idle
+    const uint16_t* col_addr;   // [TD][64]  byte address of the c2v word of the column's d-th edge (ascending check order)
+    const uint16_t* check_at;   // [64*NR]   check index handled at position 64*r + lane, 0xFFFF idle
+    const uint16_t* col_at;     // [64*NC]   information column at sorted position q, 0xFFFF idle
+    const uint16_t* col_pos;    // [k]       sorted position of information column j
+};
 
 template <class S>
 struct FastState {
-    // tables (loaded once per wave): BYTE addresses inside the wave's LDS region, packed 2 x u16
-    uint32_t rne;                                // 4 bits per row round: information edges (0 beyond m)
-    uint32_t cdeg[(S::IR + 7) / 8];              // 4 bits per column round
-    uint32_t rvar[(S::RR * kInfoSlots + 1) / 2]; // byte address of tot[var] for (round, slot)
-    uint32_t cslot[(S::IR * S::DV + 1) / 2];     // byte address of the c2v slot for (round, d)
-    // decoder input of the current attempt
-    float li[S::IR];               // information-column LLRs (column j = lane + 64 r)
-    float lp[S::RR];               // identity-column LLRs   (column k + perm[lane + 64 r])
-    // running state
-    float pv[S::RR];               // v2c of the identity edges
-    uint32_t phard;                // hard bits of the identity columns (bit r)
-    uint32_t ihard;                // hard bits of the information columns (bit r)
+    using I = ShapeInfo<S>;
+    uint32_t rv[I::TS];            // gather addresses of the check pass
+    uint32_t cs[I::TD > 0 ? I::TD : 1];   // gather addresses of the column pass
+    float li[S::NC];               // information-column LLRs (sorted position q = lane + 64 r)
+    float lp[S::NR];               // identity-column LLRs (row position p = lane + 64 r)
+    float pv[S::NR];               // v2c of the identity edges
+    float pt[S::NR];               // totals of the identity columns
 };
 
-template <int PER, class T>
-__device__ __forceinline__ uint32_t unpack16(const T& arr, int idx) {
-    uint32_t w = arr[idx >> 1];
-    return (idx & 1) ? (w >> 16) : (w & 0xffffu);
+// LDS accesses by 32-bit LDS byte address (ds_read_b32 / ds_write_b32 vaddr [+ immediate offset])
+using lds_float_ptr = __attribute__((address_space(3))) float*;
+__device__ __forceinline__ uint32_t lds_addr(const unsigned char* p) {
+    return static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const unsigned char*)p));
 }
-
+__device__ __forceinline__ float lds_f(uint32_t a) { return *(lds_float_ptr)a; }
+__device__ __forceinline__ void lds_sf(uint32_t a, float v) { *(lds_float_ptr)a = v; }
+// (the wave's LDS region starts at `lds`; absolute LDS addresses, one full VGPR each — kept opaque so
+// that the compiler does not re-pack them into 16-bit halves and pay an unpack per access)
 template <class S>
-__device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, int lane) {
-    st.rne = 0;
+__device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, const unsigned char* lds, int lane) {
+    using I = ShapeInfo<S>;
+    const uint32_t base = lds_addr(lds);
 #pragma unroll
-    for (int w = 0; w < (S::RR * kInfoSlots + 1) / 2; ++w) st.rvar[w] = 0;
+    for (int i = 0; i < I::TS; ++i) { uint32_t a = base + c.row_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.rv[i] = a; }
 #pragma unroll
-    for (int w = 0; w < (S::IR + 7) / 8; ++w) st.cdeg[w] = 0;
-#pragma unroll
-    for (int w = 0; w < (S::IR * S::DV + 1) / 2; ++w) st.cslot[w] = 0;
-    const uint32_t tot_base = static_cast<uint32_t>(fast_tot_word(c.m)) * 4u;
-#pragma unroll
-    for (int r = 0; r < S::RR; ++r) {
-        int p = lane + 64 * r;
-        uint32_t ne = (p < c.m) ? c.row_ne[p] : 0u;
-        st.rne |= ne << (4 * r);
-#pragma unroll
-        for (int s = 0; s < kInfoSlots; ++s) {
-            uint32_t a = (s < static_cast<int>(ne)) ? tot_base + 4u * c.row_var[s * c.m + p] : tot_base;
-            st.rvar[(r * kInfoSlots + s) >> 1] |= a << (((r * kInfoSlots + s) & 1) * 16);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < S::IR; ++r) {
-        int j = lane + 64 * r;
-        uint32_t d = (j < c.k) ? c.col_deg[j] : 0u;
-        st.cdeg[r >> 3] |= d << (4 * (r & 7));
-#pragma unroll
-        for (int e = 0; e < S::DV; ++e) {
-            uint32_t a = (e < static_cast<int>(d)) ? 4u * c.col_slot[e * c.k + j] : 0u;
-            st.cslot[(r * S::DV + e) >> 1] |= a << (((r * S::DV + e) & 1) * 16);
-        }
-    }
+    for (int i = 0; i < I::TD; ++i) { uint32_t a = base + c.col_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.cs[i] = a; }
 }
 
-__device__ __forceinline__ float lds_f(const unsigned char* base, uint32_t off) { return *reinterpret_cast<const float*>(base + off); }
-__device__ __forceinline__ void lds_sf(unsigned char* base, uint32_t off, float v) { *reinterpret_cast<float*>(base + off) = v; }
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {   // (mask & a) | (~mask & b)
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+
+// decoder input domain (include/ria_gpu.h): NaN -> +1e30 exactly as the reference demapper's own
+// std::min/std::max clip would map it, |x| capped at 1e30, zeros made +0.0 (the reference only ever
+// tests `x < 0` and |x|, for which -0.0 and +0.0 are the same number).
+__device__ __forceinline__ float llr_canon(float x) {
+    x = (x < 1e30f) ? x : 1e30f;
+    x = (-1e30f < x) ? x : -1e30f;
+    return x + 0.0f;
+}
 
 // Runs the decoder on the LLRs in st.li / st.lp.  Returns LDPCDecoder::lastIterations(); *ok = converged.
-// On return st.ihard holds the information hard bits of the accepted (or last) iteration.
+// On return the information-column totals of the accepted (or last) iteration are in LDS (fast_pack).
 //
 // Message flow per iteration (same arithmetic as ldpc_decoder.cpp:176-236, different bookkeeping):
-//   check pass   for every edge: v2c = clamp(tot[var] - c2v_old) (iteration 0: v2c = llr), hard bit =
-//                tot[var] < 0 (-> syndrome of the PREVIOUS iteration for free), then the min-sum update
-//                written back to the edge's slot as c2v;
+//   check pass   for every edge: v2c = clamp(tot[var] - c2v_old) (iteration 0: c2v_old = 0 and the clamp
+//                bounds are +-inf, so v2c = llr), parity ^= sign(tot[var]) (-> syndrome of the PREVIOUS
+//                iteration for free), then the min-sum update written back to the edge's slot as c2v;
 //   column pass  tot[j] = llr[j] + sum of its c2v slots in ascending check order -> ONE store per column.
-// Integer tricks keep it exact: |x| of finite floats orders like the unsigned bit pattern, so min1/min2
-// use integer min/med3; "x < 0" is taken from a float compare so that -0.0 counts as positive exactly
-// like the reference's `if (msg < 0)`.
+// Zeros stay canonical: x - y and x + y only give -0.0 from (-0.0, +-0.0) operands, the LLRs are
+// canonical and a c2v of -0.0 can only be added to or subtracted from a canonical value.
 template <class S>
 __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned char* __restrict__ lds,
                                   float factor, int max_iter, int lane, bool* ok) {
-    const int m = c.m;
-    const uint32_t tot_base = static_cast<uint32_t>(fast_tot_word(m)) * 4u;
-    const uint32_t dummy = static_cast<uint32_t>(fast_dummy_word(m, c.k) + lane) * 4u;
+    using I = ShapeInfo<S>;
+    const uint32_t lane4 = lds_addr(lds) + static_cast<uint32_t>(lane) * 4u;
     const uint32_t kInfBits = 0x7f7fffffu;  // FLT_MAX, the reference's initial min_abs
-    // tot := channel LLR of the information columns
+    const uint32_t kAbs = 0x7fffffffu;
+    // c2v := 0, tot := channel LLR of the information columns, zero words
 #pragma unroll
-    for (int r = 0; r < S::IR; ++r) {
-        int j = lane + 64 * r;
-        lds_sf(lds, (j < c.k) ? tot_base + 4u * j : dummy, st.li[r]);
-    }
+    for (int i = 0; i < I::TS; ++i) lds_sf(lane4 + 256u * i, 0.0f);
 #pragma unroll
-    for (int r = 0; r < S::RR; ++r) st.pv[r] = st.lp[r];
-    st.phard = 0; st.ihard = 0;
+    for (int r = 0; r < S::NC; ++r) lds_sf(lane4 + 4u * (I::tot_word + 64 * r), st.li[r]);
+    lds_sf(lane4 + 4u * I::zero_word, 0.0f);
+#pragma unroll
+    for (int r = 0; r < S::NR; ++r) { st.pv[r] = st.lp[r]; st.pt[r] = 0.0f; }
     wave_sync();
+    float lo = -__builtin_inff(), hi = __builtin_inff();
     int it = 0;
     bool success = false;
-    for (;; ++it) {
-        const bool last_check_only = (it == max_iter);  // trailing pass: syndrome of the final iteration
-        const bool first = (it == 0);
-        // Keep the per-lane tables opaque inside the loop: otherwise LICM hoists all 36 unpacked
-        // addresses and 36 lane masks (64-bit SGPR pairs) out of it and the kernel drowns in spills.
-        uint32_t rne = st.rne;
-        asm volatile("" : "+v"(rne));
+    for (; it < max_iter; ++it) {
         uint32_t syn = 0;
+        static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
+            constexpr int r = decltype(R_)::value;
+            constexpr int NE = S::ne(r);
+            constexpr int off = I::row_off(r);
+            float t[NE], cold[NE];
 #pragma unroll
-        for (int r = 0; r < S::RR; ++r) {
-            const int p = lane + 64 * r;
-            // 6-bit activity pattern of this row's slots (ones for s < ne), rows beyond m: none
-            uint32_t abits = (1u << ((rne >> (4 * r)) & 15u)) - 1u;
-            const uint32_t vmask = static_cast<uint32_t>((p - m) >> 31); // all ones for p < m
-            const uint32_t srow = 4u * static_cast<uint32_t>(p) & vmask;
-            // (opaque per round: the unpacked addresses must not be hoisted out of their round)
-#pragma unroll
-            for (int w = (r * kInfoSlots) / 2; w <= (r * kInfoSlots + kInfoSlots - 1) / 2; ++w) asm volatile("" : "+v"(st.rvar[w]));
-            // issue all 12 LDS reads of the round back to back (inactive slots read valid dummy addresses)
-            float t[kInfoSlots], cold[kInfoSlots];
-#pragma unroll
-            for (int s = 0; s < kInfoSlots; ++s) {
-                t[s] = lds_f(lds, unpack16<0>(st.rvar, r * kInfoSlots + s));
-                cold[s] = lds_f(lds, srow + 4u * s * m);
+            for (int s = 0; s < NE; ++s) {
+                t[s] = lds_f(st.rv[off + s]);
+                cold[s] = lds_f(lane4 + 256u * (off + s));
             }
-            uint32_t ab[kInfoSlots], sb[kInfoSlots], act[kInfoSlots];
-            uint32_t min1 = kInfBits, min2 = kInfBits, sgn = 0, par = (st.phard >> r) & 1u;
+            const uint32_t xp = f2u(st.pv[r]);            // identity edge: the last edge of the row
+            uint32_t par = f2u(st.pt[r]);
+            uint32_t sgn = xp, min1 = xp & kAbs, min2 = kInfBits;
+            uint32_t vb[NE], ab[NE];
 #pragma unroll
-            for (int s = 0; s < kInfoSlots; ++s) {
-                // sign-extended bit s of abits: all ones when the slot is active (kept opaque so that the
-                // compiler does not turn the masks back into 64-bit SGPR lane masks)
-                int am;
-                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(am) : "v"(abits), "n"(s));
-                act[s] = static_cast<uint32_t>(am);
+            for (int s = 0; s < NE; ++s) {
                 float v = t[s] - cold[s];
-                v = (v < 50.0f) ? v : 50.0f;
-                v = (-50.0f < v) ? v : -50.0f;
-                v = first ? t[s] : v;
-                par ^= ((t[s] < 0.0f) ? 1u : 0u) & act[s];
-                sb[s] = ((v < 0.0f) ? 0x80000000u : 0u) & act[s];
-                sgn ^= sb[s];
-                const uint32_t a = f2u(v) & 0x7fffffffu;
-                ab[s] = (a & act[s]) | (kInfBits & ~act[s]);
-                const uint32_t lo = min(ab[s], min1);
-                const uint32_t hi = max(ab[s], min1);
-                min2 = min(hi, min2);
-                min1 = lo;
+                v = __builtin_amdgcn_fmed3f(v, lo, hi);
+                par ^= f2u(t[s]);
+                vb[s] = f2u(v);
+                sgn ^= vb[s];
+                ab[s] = vb[s] & kAbs;
+                min2 = med3u(ab[s], min1, min2);
+                min1 = min(ab[s], min1);
             }
-            syn |= par & vmask;
-            if (!last_check_only) {   // wave-uniform
-                const float xp = st.pv[r];                // identity edge: the last edge of the row
-                const uint32_t sp = (xp < 0.0f) ? 0x80000000u : 0u;
-                sgn ^= sp;
-                const uint32_t ap = f2u(xp) & 0x7fffffffu;
-                {
-                    const uint32_t lo = min(ap, min1);
-                    const uint32_t hi = max(ap, min1);
-                    min2 = min(hi, min2);
-                    min1 = lo;
-                }
+            syn |= par;
+            // (sign * min_abs) * factor == sign * (min_abs * factor): scale the two candidates once per row
+            const uint32_t m1f = f2u(u2f(min1) * factor), m2f = f2u(u2f(min2) * factor);
 #pragma unroll
-                for (int s = 0; s < kInfoSlots; ++s) {
-                    // min over the OTHER edges: min2 if this edge holds the minimum (ties: min2 == min1)
-                    const uint32_t mn = (ab[s] == min1) ? min2 : min1;
-                    const float cv = u2f(mn | (sgn ^ sb[s])) * factor;   // (sign * min_abs) * factor
-                    const uint32_t am = act[s] & vmask;
-                    const uint32_t addr = ((srow + 4u * s * m) & am) | (dummy & ~am);
-                    lds_sf(lds, addr, cv);
-                }
-                {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
-                    const uint32_t mn = (ap == min1) ? min2 : min1;
-                    const float c2v = u2f(mn | (sgn ^ sp)) * factor;
-                    const float tot = st.lp[r] + c2v;
-                    float y = tot - c2v;
-                    y = (y < 50.0f) ? y : 50.0f;
-                    y = (-50.0f < y) ? y : -50.0f;
-                    st.pv[r] = u2f(f2u(y) & vmask);
-                    st.phard = (st.phard & ~(1u << r)) | (((tot < 0.0f) ? (1u << r) : 0u) & vmask);
-                }
+            for (int s = 0; s < NE; ++s) {
+                // min over the OTHER edges: min2 if this edge holds the minimum (ties: min2 == min1)
+                const uint32_t mn = (ab[s] == min1) ? m2f : m1f;
+                lds_sf(lane4 + 256u * (off + s), u2f(bfi(kAbs, mn, sgn ^ vb[s])));
             }
-            __builtin_amdgcn_sched_barrier(0);   // one round at a time: keeps the live set (VGPRs) small
-        }
-        if (it > 0 && __ballot(syn != 0) == 0ull) { success = true; --it; break; }
-        if (last_check_only) break;
+            {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
+                const uint32_t mn = ((xp & kAbs) == min1) ? m2f : m1f;
+                const float c2v = u2f(bfi(kAbs, mn, sgn ^ xp));
+                const float tot = st.lp[r] + c2v;
+                st.pv[r] = __builtin_amdgcn_fmed3f(tot - c2v, -50.0f, 50.0f);
+                st.pt[r] = tot;
+            }
+        });
+        if (it > 0 && __ballot(static_cast<int>(syn) < 0) == 0ull) { success = true; --it; break; }
+        lo = -50.0f; hi = 50.0f;
         wave_sync();
         // information columns: tot = llr + sum of c2v in ascending check order
-        uint32_t cd0 = st.cdeg[0];
-        asm volatile("" : "+v"(cd0));
+        static_for<0, S::NC>([&](auto R_) __attribute__((always_inline)) {
+            constexpr int r = decltype(R_)::value;
+            constexpr int DV = S::dv(r);
+            constexpr int off = I::col_off(r);
+            if constexpr (DV > 0) {
+                float cv[DV];
 #pragma unroll
-        for (int r = 0; r < S::IR; ++r) {
-            const int j = lane + 64 * r;
-            const int deg = static_cast<int>((((r < 8) ? cd0 : st.cdeg[r >> 3]) >> (4 * (r & 7))) & 15u);
-            float tot = st.li[r];
+                for (int d = 0; d < DV; ++d) cv[d] = lds_f(st.cs[off + d]);
+                float tot = st.li[r];
 #pragma unroll
-            for (int w = (r * S::DV) / 2; w <= (r * S::DV + S::DV - 1) / 2; ++w) asm volatile("" : "+v"(st.cslot[w]));
-            float cv[S::DV];
-#pragma unroll
-            for (int d = 0; d < S::DV; ++d) cv[d] = lds_f(lds, unpack16<0>(st.cslot, r * S::DV + d));
-#pragma unroll
-            for (int d = 0; d < S::DV; ++d) tot = (d < deg) ? tot + cv[d] : tot;
-            const uint32_t jm = static_cast<uint32_t>((j - c.k) >> 31);
-            lds_sf(lds, ((tot_base + 4u * j) & jm) | (dummy & ~jm), tot);
-            st.ihard = (st.ihard & ~(1u << r)) | ((tot < 0.0f) ? (1u << r) : 0u);
-            if (r & 1) __builtin_amdgcn_sched_barrier(0);
-        }
+                for (int d = 0; d < DV; ++d) tot = tot + cv[d];
+                lds_sf(lane4 + 4u * (I::tot_word + 64 * r), tot);
+            }
+        });
         wave_sync();
+    }
+    if (!success) {   // syndrome of the final iteration
+        uint32_t syn = 0;
+        static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
+            constexpr int r = decltype(R_)::value;
+            constexpr int off = I::row_off(r);
+            uint32_t par = f2u(st.pt[r]);
+#pragma unroll
+            for (int s = 0; s < S::ne(r); ++s) par ^= f2u(lds_f(st.rv[off + s]));
+            syn |= par;
+        });
+        if (max_iter > 0 && __ballot(static_cast<int>(syn) < 0) == 0ull) { success = true; it = max_iter - 1; }
     }
     *ok = success;
     return success ? it : max_iter;
 }
 
-// information hard bits -> bytes, MSB first (decodeBP's packing); scratch: >= 8*IR bytes of LDS
+// information hard bits -> bytes, MSB first (decodeBP's packing), from the column totals in LDS;
+// scratch: the c2v area of the wave's LDS region (>= 8*ceil(k/64) bytes, free once the decode is over)
 template <class S>
-__device__ inline void fast_pack(const FastState<S>& st, const FastCode& c, uint8_t* scratch, uint8_t* out, int nbytes,
+__device__ inline void fast_pack(const FastState<S>& st, const FastCode& c, unsigned char* lds, uint8_t* out, int nbytes,
                                  int lane) {
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(scratch);
-#pragma unroll
-    for (int r = 0; r < S::IR; ++r) {
-        bool bit = ((st.ihard >> r) & 1u) && (lane + 64 * r < c.k);
+    using I = ShapeInfo<S>;
+    (void)st;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(lds);
+    const int nr = (c.k + 63) / 64;
+    for (int r = 0; r < nr; ++r) {
+        const int j = lane + 64 * r;
+        bool bit = false;
+        if (j < c.k) bit = (f2u(lds_f(lds_addr(lds) + 4u * (I::tot_word + c.col_pos[j]))) >> 31) != 0u;
         unsigned long long mk = __ballot(bit);
         if (lane == 0) masks[r] = mk;
     }
     wave_sync();
-    for (int b = lane; b < nbytes; b += 64) out[b] = static_cast<uint8_t>(__brev(static_cast<unsigned>(scratch[b])) >> 24);
+    for (int b = lane; b < nbytes; b += 64) out[b] = static_cast<uint8_t>(__brev(static_cast<unsigned>(lds[b])) >> 24);
     wave_sync();
 }
 
@@ -311,13 +314,22 @@ struct FastDecodeArgs {
     uint8_t* res_bytes;      // [4*n_frames][5][bytes_per_cw]
 };
 
+constexpr float kIdleRowLlr = 1e30f;   // idle row lanes: a parity bit that is certainly 0 keeps their syndrome term 0
+
+// gathers one codeword's decoder input straight from the frame's interleaved soft bits
 template <class S>
 __device__ inline void fast_gather_llr(FastState<S>& st, const FastCode& c, const float* fl, const uint16_t* gather,
                                        int cw, int lane) {
 #pragma unroll
-    for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? fl[gather[cw * 648 + j]] : 0.0f; }
+    for (int r = 0; r < S::NC; ++r) {
+        const uint32_t j = c.col_at[lane + 64 * r];
+        st.li[r] = (j != 0xFFFFu) ? llr_canon(fl[gather[cw * 648 + j]]) : 0.0f;
+    }
 #pragma unroll
-    for (int r = 0; r < S::RR; ++r) { int p = lane + 64 * r; st.lp[r] = (p < c.m) ? fl[gather[cw * 648 + c.k + c.perm[p]]] : 0.0f; }
+    for (int r = 0; r < S::NR; ++r) {
+        const uint32_t i = c.check_at[lane + 64 * r];
+        st.lp[r] = (i != 0xFFFFu) ? llr_canon(fl[gather[cw * 648 + c.k + i]]) : kIdleRowLlr;
+    }
 }
 
 // decode codeword `fc` (= frame*4 + cw) with factor index f and record the result
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(64) void fast_primary_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     FastState<S> st;
-    fast_load_tables(st, A.c, lane);
+    fast_load_tables(st, A.c, smem, lane);
     fast_unit(st, A, smem, blockIdx.x, 0, lane);
 }
 
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     const unsigned u = blockIdx.x;
     if (u >= A.ctl->n_list1 * 4u) return;
     FastState<S> st;
-    fast_load_tables(st, A.c, lane);
+    fast_load_tables(st, A.c, smem, lane);
     fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
 }
 
@@ -429,18 +441,25 @@ __device__ inline float fast_perturb(FastState<S>& st, const FastCode& c, const 
         return v + (nz * sigma + 0.0f);
     };
 #pragma unroll
-    for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? tf(base_i[r], normal[j]) : 0.0f; }
+    for (int r = 0; r < S::NC; ++r) {
+        const uint32_t j = c.col_at[lane + 64 * r];
+        st.li[r] = (j != 0xFFFFu) ? llr_canon(tf(base_i[r], normal[j])) : 0.0f;
+    }
 #pragma unroll
-    for (int r = 0; r < S::RR; ++r) { int p = lane + 64 * r; st.lp[r] = (p < c.m) ? tf(base_p[r], normal[c.k + c.perm[p]]) : 0.0f; }
+    for (int r = 0; r < S::NR; ++r) {
+        const uint32_t i = c.check_at[lane + 64 * r];
+        st.lp[r] = (i != 0xFFFFu) ? llr_canon(tf(base_p[r], normal[c.k + i])) : kIdleRowLlr;
+    }
     wave_sync();
     return factor;
 }
 
-template <class S>
-__device__ inline uint32_t fast_hash16(const FastState<S>& st) {  // frame_v2.cpp:1391-1396
+// hash of the bit patterns of the codeword's first 16 LLRs (frame_v2.cpp:1391-1396)
+__device__ inline uint32_t fast_hash16(const float* fl, const uint16_t* gather, int cw, int lane) {
+    const uint32_t mine = f2u(fl[gather[cw * 648 + (lane & 15)]]);
     uint32_t h = 0;
     for (int j = 0; j < 16; ++j) {
-        uint32_t u = f2u(__shfl(st.li[0], j));
+        uint32_t u = __shfl(mine, j);
         h ^= u + 0x9e3779b9u + (h << 6) + (h >> 2);
     }
     return h;
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
     const unsigned int total = n_entries * 34u;
     if (total == 0) return;
     FastState<S> st;
-    fast_load_tables(st, c, lane);
+    fast_load_tables(st, c, smem, lane);
     for (;;) {
         unsigned int u = 0;
         if (lane == 0) u = atomicAdd(&A.ctl->next_unit, 1u);
@@ -470,12 +489,12 @@ __global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
         if (b < a) continue;  // an earlier attempt already succeeded: this one can never be chosen
         const unsigned int fc = A.entries[e];
         fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
-        float bi[S::IR], bp[S::RR];
+        float bi[S::NC], bp[S::NR];
 #pragma unroll
-        for (int r = 0; r < S::IR; ++r) bi[r] = st.li[r];
+        for (int r = 0; r < S::NC; ++r) bi[r] = st.li[r];
 #pragma unroll
-        for (int r = 0; r < S::RR; ++r) bp[r] = st.lp[r];
-        uint32_t h = fast_hash16(st);
+        for (int r = 0; r < S::NR; ++r) bp[r] = st.lp[r];
+        uint32_t h = fast_hash16(A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
         (void)fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
@@ -501,14 +520,14 @@ __global__ __launch_bounds__(64) void fast_finalize_kernel(FastDecodeArgs A) {
             continue;
         }
         FastState<S> st;
-        fast_load_tables(st, c, lane);
+        fast_load_tables(st, c, smem, lane);
         fast_gather_llr(st, c, A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, cw, lane);
-        float bi[S::IR], bp[S::RR];
+        float bi[S::NC], bp[S::NR];
 #pragma unroll
-        for (int r = 0; r < S::IR; ++r) bi[r] = st.li[r];
+        for (int r = 0; r < S::NC; ++r) bi[r] = st.li[r];
 #pragma unroll
-        for (int r = 0; r < S::RR; ++r) bp[r] = st.lp[r];
-        uint32_t h = fast_hash16(st);
+        for (int r = 0; r < S::NR; ++r) bp[r] = st.lp[r];
+        uint32_t h = fast_hash16(A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, cw, lane);
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
         int it = fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
@@ -599,7 +618,7 @@ __global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
     const unsigned u = blockIdx.x;
     if (u >= *R.n_list2) return;
     FastState<S> st;
-    fast_load_tables(st, R.d.c, threadIdx.x);
+    fast_load_tables(st, R.d.c, smem, threadIdx.x);
     const unsigned e = R.list2[u];
     fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
 }
@@ -632,14 +651,14 @@ __global__ __launch_bounds__(64) void fast_rows_kernel(FastCode c, const float* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     FastState<S> st;
-    fast_load_tables(st, c, lane);
+    fast_load_tables(st, c, smem, lane);
     const int nb = (c.k + 7) / 8;
     for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
         const float* l = llr + static_cast<size_t>(cw) * 648;
 #pragma unroll
-        for (int r = 0; r < S::IR; ++r) { int j = lane + 64 * r; st.li[r] = (j < c.k) ? l[j] : 0.0f; }
+        for (int r = 0; r < S::NC; ++r) { const uint32_t j = c.col_at[lane + 64 * r]; st.li[r] = (j != 0xFFFFu) ? llr_canon(l[j]) : 0.0f; }
 #pragma unroll
-        for (int r = 0; r < S::RR; ++r) { int p = lane + 64 * r; st.lp[r] = (p < c.m) ? l[c.k + c.perm[p]] : 0.0f; }
+        for (int r = 0; r < S::NR; ++r) { const uint32_t i = c.check_at[lane + 64 * r]; st.lp[r] = (i != 0xFFFFu) ? llr_canon(l[c.k + i]) : kIdleRowLlr; }
         bool ok;
         int it = fast_decode(st, c, smem, factor, max_iter, lane, &ok);
         fast_pack(st, c, smem, out + static_cast<size_t>(cw) * nb, nb, lane);

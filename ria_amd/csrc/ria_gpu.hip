@@ -40,10 +40,10 @@ struct ria_gpu {
     void* d_tx_const = nullptr;
     // workspace
     float* d_llr_ws = nullptr;            // max_batch * llrs_per_frame (fused path)
-    LdpcDev ldpc_dev{};
     FastCode fast{};
-    FastTables ftab;
-    void* d_f_perm = nullptr; void* d_f_row_ne = nullptr; void* d_f_row_var = nullptr; void* d_f_col_deg = nullptr; void* d_f_col_slot = nullptr;
+    CoreTables ftab;
+    void* d_f_row_addr = nullptr; void* d_f_col_addr = nullptr; void* d_f_check_at = nullptr; void* d_f_col_at = nullptr; void* d_f_col_pos = nullptr;
+    int wave_lds = 0;
     DecodeCtl* d_ctl = nullptr;           // cascade work-list control block
     unsigned int* d_entries = nullptr;    // [4 * ws_frames]
     unsigned int* d_best = nullptr;       // [4 * ws_frames]
@@ -110,14 +110,17 @@ static void dispatch_shape(int rate, F&& f) {
         default: f(ShapeR12{}); break;
     }
 }
-static bool shape_fits(int rate, const LdpcCode& c) {
+// the compiled round structure must be the one host_tables.hpp derives from the generated H
+static bool shape_fits(int rate, const CoreTables& t, int* wave_lds) {
     bool ok = false;
     dispatch_shape(rate, [&](auto s) {
         using S = decltype(s);
-        ok = (c.m + 63) / 64 <= S::RR && (c.k + 63) / 64 <= S::IR && c.max_col_deg <= S::DV && S::RR <= 8;
-        int max_row = 0;
-        for (auto d : c.row_deg) max_row = std::max<int>(max_row, d);
-        ok = ok && max_row <= kInfoSlots + 1;
+        using I = ShapeInfo<S>;
+        ok = static_cast<int>(t.ne.size()) == S::NR && static_cast<int>(t.dv.size()) == S::NC;
+        for (int r = 0; ok && r < S::NR; ++r) ok = t.ne[r] == S::ne(r);
+        for (int r = 0; ok && r < S::NC; ++r) ok = t.dv[r] == S::dv(r);
+        ok = ok && t.ts == I::TS && t.td == I::TD && t.tot_word == I::tot_word && t.zero_word == I::zero_word && 4 * I::words <= 65536;
+        *wave_lds = I::lds_bytes;
     });
     return ok;
 }
@@ -136,15 +139,15 @@ static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     h->ws_frames = n_frames;
     return hipSuccess;
 }
-static void set_fast_attributes(int rate, int m, int k) {
+static void set_fast_attributes(int rate, int wb) {
     dispatch_shape(rate, [&](auto s) {
         using S = decltype(s);
-        int wb = fast_wave_lds_bytes(m, k);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_primary_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_finalize_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(recovery_fill_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
     });
 }
 
@@ -226,7 +229,7 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
 #define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
     R_TRY(hipMemsetAsync(h->d_rctl, 0, 16, s));
     hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
-    const int wb = fast_wave_lds_bytes(h->fast.m, h->fast.k);
+    const int wb = h->wave_lds;
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
         hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(n_frames * 16), dim3(64), wb, s, R);
@@ -313,7 +316,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
                     h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
                     h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
-                    h->d_f_perm, h->d_f_row_ne, h->d_f_row_var, h->d_f_col_deg, h->d_f_col_slot};
+                    h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
@@ -367,10 +370,6 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
         }                                                                                             \
     } while (0)
 
-    CREATE_TRY(upload(&h->d_row_deg, h->code.row_deg));
-    CREATE_TRY(upload(&h->d_row_var, h->code.row_var));
-    CREATE_TRY(upload(&h->d_col_deg, h->code.col_deg));
-    CREATE_TRY(upload(&h->d_col_slot, h->code.col_slot));
     CREATE_TRY(upload(&h->d_gather, build_rx_gather(g.bits_per_symbol, true)));
     CREATE_TRY(upload(&h->d_gather_nochan, build_rx_gather(g.bits_per_symbol, false)));
     {
@@ -400,37 +399,21 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_llr_ws),
                          static_cast<size_t>(h->cfg.max_batch) * g.llrs_per_frame * sizeof(float)));
 
-    LdpcDev& L = h->ldpc_dev;
-    L.k = h->code.k; L.m = h->code.m; L.n = h->code.n; L.max_col_deg = h->code.max_col_deg;
-    L.max_iter = g.ldpc_max_iterations; L.bytes_per_cw = g.bytes_per_codeword;
-    L.row_deg = static_cast<const uint8_t*>(h->d_row_deg);
-    L.row_var = static_cast<const uint16_t*>(h->d_row_var);
-    L.col_deg = static_cast<const uint8_t*>(h->d_col_deg);
-    L.col_slot = static_cast<const uint16_t*>(h->d_col_slot);
-
-    h->ftab = build_fast_tables(h->code);
-    CREATE_TRY(upload(&h->d_f_perm, h->ftab.perm));
-    CREATE_TRY(upload(&h->d_f_row_ne, h->ftab.row_ne));
-    CREATE_TRY(upload(&h->d_f_row_var, h->ftab.row_var));
-    CREATE_TRY(upload(&h->d_f_col_deg, h->ftab.col_deg));
-    CREATE_TRY(upload(&h->d_f_col_slot, h->ftab.col_slot));
-    h->fast.k = L.k; h->fast.m = L.m; h->fast.max_iter = L.max_iter; h->fast.bytes_per_cw = L.bytes_per_cw;
-    h->fast.perm = static_cast<const uint16_t*>(h->d_f_perm);
-    h->fast.row_ne = static_cast<const uint8_t*>(h->d_f_row_ne);
-    h->fast.row_var = static_cast<const uint16_t*>(h->d_f_row_var);
-    h->fast.col_deg = static_cast<const uint8_t*>(h->d_f_col_deg);
-    h->fast.col_slot = static_cast<const uint16_t*>(h->d_f_col_slot);
-    std::memcpy(h->fast.round_ne, h->ftab.round_ne, 8);
-    std::memcpy(h->fast.round_cd, h->ftab.round_cd, 16);
-    if (!shape_fits(cfg->code_rate, h->code)) { ria_gpu_destroy(h); return RIA_ERR_UNSUPPORTED; }
-    set_fast_attributes(cfg->code_rate, L.m, L.k);
+    h->ftab = build_core_tables(h->code);
+    CREATE_TRY(upload(&h->d_f_row_addr, h->ftab.row_addr));
+    CREATE_TRY(upload(&h->d_f_col_addr, h->ftab.col_addr));
+    CREATE_TRY(upload(&h->d_f_check_at, h->ftab.check_at));
+    CREATE_TRY(upload(&h->d_f_col_at, h->ftab.col_at));
+    CREATE_TRY(upload(&h->d_f_col_pos, h->ftab.col_pos));
+    h->fast.k = h->code.k; h->fast.m = h->code.m; h->fast.max_iter = g.ldpc_max_iterations; h->fast.bytes_per_cw = g.bytes_per_codeword;
+    h->fast.row_addr = static_cast<const uint16_t*>(h->d_f_row_addr);
+    h->fast.col_addr = static_cast<const uint16_t*>(h->d_f_col_addr);
+    h->fast.check_at = static_cast<const uint16_t*>(h->d_f_check_at);
+    h->fast.col_at = static_cast<const uint16_t*>(h->d_f_col_at);
+    h->fast.col_pos = static_cast<const uint16_t*>(h->d_f_col_pos);
+    if (!shape_fits(cfg->code_rate, h->ftab, &h->wave_lds)) { ria_gpu_destroy(h); return RIA_ERR_UNSUPPORTED; }
+    set_fast_attributes(cfg->code_rate, h->wave_lds);
     CREATE_TRY(ensure_decode_ws(h, h->cfg.max_batch));
-    // dynamic LDS above 64 KiB must be opted into per kernel
-    int frame_lds = 4 * ldpc_wave_lds_bytes(L.m) + kFrameSharedBytes;
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_frames_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, frame_lds));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_decode_rows_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ldpc_wave_lds_bytes(L.m)));
     CREATE_TRY(demod_set_attributes());
 #undef CREATE_TRY
     *out = h;
@@ -453,7 +436,7 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
     HIP_TRY(h, hipSetDevice(h->device));
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), fast_wave_lds_bytes(h->fast.m, h->fast.k),
+        hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), h->wave_lds,
                            static_cast<hipStream_t>(stream), h->fast, llr_dev, n_cw, max_iterations, min_sum_factor,
                            out_dev, ok_dev, iters_dev);
     });
@@ -486,7 +469,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.res_bytes = h->d_res_bytes;
     if ((e = hipMemsetAsync(h->d_ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-    const int wb = fast_wave_lds_bytes(h->fast.m, h->fast.k);
+    const int wb = h->wave_lds;
     static const bool dbg = getenv("RIA_DEBUG_SYNC") != nullptr;   // stage-by-stage sync + trace on stderr
     auto stage = [&](const char* name) {
         if (!dbg) return;
