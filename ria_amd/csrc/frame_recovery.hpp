@@ -13,6 +13,8 @@
 #include <cstring>
 #include <vector>
 
+#include "sort_exact.hpp"
+
 namespace ria {
 
 struct Crc16Tables {
@@ -101,51 +103,11 @@ struct FrameRecovery {
         return verify(fd, n);
     }
 
-    struct Suspect { int frame_bit; float abs_llr; };
-    // libstdc++ std::sort (introsort, insertion threshold 16) with comparator a.abs_llr < b.abs_llr:
-    // the order of equal keys decides which suspects are tried first (frame_v2.cpp:1717-1718).
-    static bool lt(const Suspect& a, const Suspect& b) { return a.abs_llr < b.abs_llr; }
-    static void linear_insert(Suspect* last) {
-        Suspect val = *last;
-        Suspect* next = last - 1;
-        while (lt(val, *next)) { *last = *next; last = next; --next; }
-        *last = val;
-    }
-    static void insertion(Suspect* first, Suspect* last) {
-        if (first == last) return;
-        for (Suspect* i = first + 1; i != last; ++i) {
-            if (lt(*i, *first)) { Suspect v = *i; std::memmove(first + 1, first, (i - first) * sizeof(Suspect)); *first = v; }
-            else linear_insert(i);
-        }
-    }
-    static void introsort(Suspect* first, Suspect* last, int depth) {
-        while (last - first > 16) {
-            if (depth == 0) { std::make_heap(first, last, lt); std::sort_heap(first, last, lt); return; }
-            --depth;
-            Suspect *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1;
-            if (lt(*a, *b)) { if (lt(*b, *c)) std::swap(*first, *b); else if (lt(*a, *c)) std::swap(*first, *c); else std::swap(*first, *a); }
-            else { if (lt(*a, *c)) std::swap(*first, *a); else if (lt(*b, *c)) std::swap(*first, *c); else std::swap(*first, *b); }
-            Suspect *lo = first + 1, *hi = last;
-            for (;;) {
-                while (lt(*lo, *first)) ++lo;
-                --hi;
-                while (lt(*first, *hi)) --hi;
-                if (!(lo < hi)) break;
-                std::swap(*lo, *hi);
-                ++lo;
-            }
-            introsort(lo, last, depth);
-            last = lo;
-        }
-    }
+    // suspects are ordered by libstdc++'s std::sort with comparator a.abs_llr < b.abs_llr: the order of
+    // equal keys decides which suspects are tried first (frame_v2.cpp:1717-1718) -> sort_exact.hpp
     static void sort_suspects(std::vector<Suspect>& v) {
-        int n = static_cast<int>(v.size());
-        if (n == 0) return;
-        int lg = 0;
-        for (int t = n; t > 1; t >>= 1) ++lg;
-        introsort(v.data(), v.data() + n, 2 * lg);
-        if (n > 16) { insertion(v.data(), v.data() + 16); for (Suspect* i = v.data() + 16; i != v.data() + n; ++i) linear_insert(i); }
-        else insertion(v.data(), v.data() + n);
+        int stack[192];
+        sort_exact_prefix(v.data(), static_cast<int>(v.size()), 30, stack, suspect_lt);
     }
 
     // Stage 1 (frame_v2.cpp:1579-1834): CRC-guided bit-flip searches.  cw: the four decoded codeword

@@ -586,63 +586,6 @@ __global__ __launch_bounds__(256) void frame_validate_kernel(const uint8_t* __re
     }
 }
 
-// ------------------------------------------------------------------------------------------------ CRC recovery prep
-// (frame_v2.cpp:1564-1880 runs on the host, ria_amd/csrc/frame_recovery.hpp; these kernels stage its inputs)
-struct RecoveryArgs {
-    FastDecodeArgs d;
-    unsigned int* n_flagged;     // counter
-    unsigned int* flagged;       // [n_frames] frame indices needing recovery
-    unsigned int* n_list2;       // counter
-    unsigned int* list2;         // [16*n_frames] (fc << 3) | factor index
-    uint8_t* info_c;             // [n_flagged][4*bpc]
-    float* rows_c;               // [n_flagged][4][648] decoder-order LLRs
-    uint8_t* redec_ok;           // [n_flagged][4 factors][4 cw]   (factor order of the reference: 0.75, 0.625, 0.5, 0.875)
-    uint8_t* redec_bytes;        // [n_flagged][4][4][bpc]
-};
-
-// one thread per frame: list the frames that need recovery and the (codeword, factor) decodes the
-// fallback stage (frame_v2.cpp:1836-1866) will want that the result table does not hold yet
-__global__ void recovery_list_kernel(RecoveryArgs R) {
-    int frame = blockIdx.x * blockDim.x + threadIdx.x;
-    if (frame >= R.d.n_frames || !R.d.status[frame].needs_recovery) return;
-    R.flagged[atomicAdd(R.n_flagged, 1u)] = static_cast<unsigned>(frame);
-    for (int cw = 0; cw < 4; ++cw) {
-        unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
-        for (int f = 1; f <= 4; ++f)
-            if (R.d.res[fc].state[f] == 0) R.list2[atomicAdd(R.n_list2, 1u)] = (fc << 3) | static_cast<unsigned>(f);
-    }
-}
-template <class S>
-__global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned u = blockIdx.x;
-    if (u >= *R.n_list2) return;
-    FastState<S> st;
-    fast_load_tables(st, R.d.c, smem, threadIdx.x);
-    const unsigned e = R.list2[u];
-    fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
-}
-// one workgroup per flagged frame: compact copies of everything the host stage reads
-__global__ __launch_bounds__(256) void recovery_gather_kernel(RecoveryArgs R) {
-    const unsigned q = blockIdx.x;
-    if (q >= *R.n_flagged) return;
-    const unsigned frame = R.flagged[q];
-    const int bpc = R.d.c.bytes_per_cw, ib = 4 * bpc;
-    for (int i = threadIdx.x; i < ib; i += 256) R.info_c[static_cast<size_t>(q) * ib + i] = R.d.info_out[static_cast<size_t>(frame) * ib + i];
-    const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
-    for (int i = threadIdx.x; i < 4 * 648; i += 256) R.rows_c[static_cast<size_t>(q) * 4 * 648 + i] = fl[R.d.gather[i]];
-    const int forder[4] = {2, 3, 4, 1};   // reference tries 0.75, 0.625, 0.5, 0.875 (frame_v2.cpp:1837)
-    if (threadIdx.x < 16) {
-        int at = threadIdx.x >> 2, cw = threadIdx.x & 3;
-        R.redec_ok[static_cast<size_t>(q) * 16 + threadIdx.x] = R.d.res[frame * 4u + cw].state[forder[at]] == 2 ? 1 : 0;
-    }
-    for (int i = threadIdx.x; i < 16 * bpc; i += 256) {
-        int slot = i / bpc, b = i - slot * bpc, at = slot >> 2, cw = slot & 3;
-        R.redec_bytes[static_cast<size_t>(q) * 16 * bpc + i] =
-            R.d.res_bytes[(static_cast<size_t>(frame * 4u + cw) * kNumFactors + forder[at]) * bpc + b];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ raw rows
 template <class S>
 __global__ __launch_bounds__(64) void fast_rows_kernel(FastCode c, const float* __restrict__ llr, int n_cw, int max_iter,

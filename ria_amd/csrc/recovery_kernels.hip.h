@@ -1,0 +1,353 @@
+// ria_amd/csrc/recovery_kernels.hip.h — the "LDPC false positive" recovery of v2::decodeFixedFrame
+// (src/protocol/frame_v2.cpp:1564-1880) on the GPU: one wavefront per flagged frame.
+//
+// A frame is flagged when all four codewords converged but the frame CRC fails.  The reference then
+//   stage 1  searches CRC-guided bit flips (header bits; single bit; CRC bits; pairs, triples and
+//            quadruples of the 30 / 15 least reliable "suspect" bits, std::sort order), and
+//   stage 2  re-decodes each codeword with min-sum factors {0.75, 0.625, 0.5, 0.875} and accepts the
+//            first replacement that makes the frame verify.
+// Everything is a search with a first-hit-wins order, so the wave evaluates the cheap linear filters
+// (CRC syndromes are linear in the flipped bits) for 64 candidates at a time, takes the hits in the
+// reference's loop order, and runs the full reassemble+verify only for those.  The one sequential
+// piece, libstdc++'s introsort (its tie order decides the suspects), runs on lane 0 over LDS and only
+// as far as the first 30 positions need (sort_exact.hpp).  The stage-2 decodes are the rows of the
+// factor result table that phase 0 fills (ldpc_fast.hip.h), completed by recovery_fill_kernel.
+// frame_recovery.hpp holds the same logic for the host; tests run both and compare.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ldpc_fast.hip.h"
+#include "sort_exact.hpp"
+
+namespace ria {
+
+struct RecCtx {            // wave-uniform view of one frame's working set (all pointers into LDS)
+    uint8_t* cw;           // [4][68] decoded codeword payloads, modified in place when recovered
+    uint8_t* fd;           // [272] reassembled frame
+    uint8_t* trial;        // [272]
+    Suspect* sus;          // [4 * bpc * 8]
+    int* stack;            // [192]
+    uint16_t* sd;          // [32]
+    int bpc;
+    const uint16_t* crc_bit;
+    const uint16_t* crc_init;
+    int lane;
+};
+
+__device__ inline bool rec_parse_header(const RecCtx& x, const uint8_t* d, int len, bool* ctl, int* plen) {  // frame_v2.cpp:1195-1252
+    if (len < 20) return false;
+    if (d[0] != 0x55 || d[1] != 0x4C) return false;
+    const int t = d[2];
+    *ctl = (t == 0x10 || t == 0x11 || t == 0x16 || t == 0x17 || t == 0x20 || t == 0x21 || t == 0x15 || t == 0x40);
+    if (*ctl) {
+        if (crc16_wave(d, 18, x.crc_bit, x.crc_init, x.lane) != static_cast<uint32_t>((d[18] << 8) | d[19])) return false;
+        *plen = 0;
+    } else {
+        *plen = (d[13] << 8) | d[14];
+        if (crc16_wave(d, 15, x.crc_bit, x.crc_init, x.lane) != static_cast<uint32_t>((d[15] << 8) | d[16])) return false;
+    }
+    return true;
+}
+// CodewordStatus::reassemble + reassembleCodewords (frame_v2.cpp:1030-1063, :959-989), all CWs decoded
+__device__ inline int rec_reassemble(const RecCtx& x, uint8_t* out) {
+    bool ctl; int plen;
+    wave_sync();
+    if (!rec_parse_header(x, x.cw, x.bpc, &ctl, &plen)) return 0;
+    const int expected = ctl ? 20 : 17 + plen + 2;
+    int n = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int remaining = expected - n;
+        if (remaining == 0) break;
+        const uint8_t* src = x.cw + i * 68;
+        int avail = x.bpc;
+        if (i != 0 && src[0] == 0xD5) { src += 2; avail -= 2; }
+        const int c = remaining < avail ? remaining : avail;
+        for (int b = x.lane; b < c; b += 64) out[n + b] = src[b];
+        n += c;
+    }
+    wave_sync();
+    return n;
+}
+__device__ inline bool rec_verify(const RecCtx& x, const uint8_t* d, int len) {  // verifyFrame lambda, frame_v2.cpp:1583-1589
+    bool ctl; int plen;
+    if (len == 0 || !rec_parse_header(x, d, len, &ctl, &plen)) return false;
+    if (ctl) return true;
+    const int sz = 17 + plen + 2;
+    if (len < sz) return false;
+    return crc16_wave(d, sz - 2, x.crc_bit, x.crc_init, x.lane) == static_cast<uint32_t>((d[sz - 2] << 8) | d[sz - 1]);
+}
+__device__ inline bool rec_try(const RecCtx& x) {
+    const int tl = rec_reassemble(x, x.trial);
+    return rec_verify(x, x.trial, tl);
+}
+__device__ inline void rec_flip(const RecCtx& x, int byte_index, int bit) {   // wave-uniform arguments
+    wave_sync();
+    if (x.lane == 0) x.cw[byte_index] ^= static_cast<uint8_t>(1u << bit);
+    wave_sync();
+}
+
+// Stage 1 (frame_v2.cpp:1579-1834).  llr(c, i): decoder-order LLR i of codeword c.
+template <class LlrFn>
+__device__ inline bool rec_search(const RecCtx& x, LlrFn llr) {
+    const int bpc = x.bpc, lane = x.lane;
+    const int flen = rec_reassemble(x, x.fd);
+    if (flen == 0) {
+        // case 1: header CRC error in CW0.  hdr_ok() = magic bytes match && CRC(bytes 0..14) == bytes 15..16;
+        // both are linear in the flipped bits: per-bit deltas dh (header CRC syndrome) and dm (magic).
+        const int tb = bpc * 8;
+        const uint8_t* c0 = x.cw;
+        const uint32_t hsyn = crc16_wave(c0, 15, x.crc_bit, x.crc_init, lane) ^ static_cast<uint32_t>((c0[15] << 8) | c0[16]);
+        const uint32_t msyn = static_cast<uint32_t>((c0[0] << 8) | c0[1]) ^ 0x554Cu;
+        auto dh = [&](int b) -> uint32_t {
+            const int by = b >> 3, bit = b & 7;
+            if (by < 15) return x.crc_bit[(14 - by) * 8 + bit];
+            if (by == 15) return 1u << (8 + bit);
+            if (by == 16) return 1u << bit;
+            return 0u;
+        };
+        auto dm = [&](int b) -> uint32_t {
+            const int by = b >> 3, bit = b & 7;
+            if (by == 0) return 1u << (8 + bit);
+            if (by == 1) return 1u << bit;
+            return 0u;
+        };
+        for (int base = 0; base < tb; base += 64) {          // single bit, ascending bit index
+            const int b = base + lane;
+            unsigned long long hits = __ballot(b < tb && (hsyn ^ dh(b)) == 0u && (msyn ^ dm(b)) == 0u);
+            while (hits) {
+                const int bb = base + __builtin_ctzll(hits);
+                hits &= hits - 1;
+                rec_flip(x, bb >> 3, bb & 7);
+                if (rec_try(x)) return true;
+                rec_flip(x, bb >> 3, bb & 7);
+            }
+        }
+        for (int b1 = 0; b1 < tb; ++b1) {                    // pairs b1 < b2, b2 ascending inside b1
+            const uint32_t h1 = hsyn ^ dh(b1), m1 = msyn ^ dm(b1);
+            // only bits of the first 17 bytes move either syndrome: beyond them a second bit can cancel
+            // nothing, so a hit there needs h1 == 0 && m1 == 0 already
+            for (int base = b1 + 1; base < tb; base += 64) {
+                const int b2 = base + lane;
+                unsigned long long hits = __ballot(b2 < tb && (h1 ^ dh(b2)) == 0u && (m1 ^ dm(b2)) == 0u);
+                while (hits) {
+                    const int bb = base + __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    rec_flip(x, b1 >> 3, b1 & 7);
+                    rec_flip(x, bb >> 3, bb & 7);
+                    if (rec_try(x)) return true;
+                    rec_flip(x, bb >> 3, bb & 7);
+                    rec_flip(x, b1 >> 3, b1 & 7);
+                }
+            }
+        }
+        return false;
+    }
+    // case 2: frame CRC error
+    bool ctl; int plen;
+    if (!rec_parse_header(x, x.fd, flen, &ctl, &plen) || ctl) return false;
+    const int expected = 17 + plen + 2;
+    if (flen < expected) return false;
+    const uint32_t stored = static_cast<uint32_t>((x.fd[expected - 2] << 8) | x.fd[expected - 1]);
+    const int data_bytes = expected - 2, data_bits = data_bytes * 8;
+    const uint32_t syn = stored ^ crc16_wave(x.fd, data_bytes, x.crc_bit, x.crc_init, lane);
+    auto delta = [&](int p) -> uint32_t { return x.crc_bit[(data_bytes - 1 - (p >> 3)) * 8 + (p & 7)]; };
+    auto fix = [&](int p) {   // frame bit -> codeword byte, the reference's own (un-stripped) mapping
+        const int fb = p >> 3, c = fb / bpc;
+        if (c < 4) rec_flip(x, c * 68 + fb % bpc, p & 7);
+    };
+    for (int base = 0; base < data_bits; base += 64) {       // single data bit: accepted without re-verification
+        const int p = base + lane;
+        unsigned long long hits = __ballot(p < data_bits && delta(p) == syn && (p >> 3) / bpc < 4);
+        if (hits) { fix(base + __builtin_ctzll(hits)); return true; }
+    }
+    for (int bit = 0; bit < 16; ++bit)                        // a bit of the stored CRC itself
+        if (syn == (1u << bit)) {
+            const int fb = (bit >= 8) ? expected - 2 : expected - 1, c = fb / bpc;
+            if (c < 4) { rec_flip(x, c * 68 + fb % bpc, bit & 7); return true; }
+        }
+    // suspects: decoded bit (LSB-first index, as the reference reads it) differs from the channel's hard decision
+    int ns_all = 0;
+    const int cw_bits = (bpc * 8 < 648) ? bpc * 8 : 648;
+    for (int c = 0; c < 4; ++c)
+        for (int base = 0; base < cw_bits; base += 64) {
+            const int i = base + lane;
+            bool is = false;
+            float l = 0.0f;
+            int fbit = 0;
+            if (i < cw_bits) {
+                fbit = c * bpc * 8 + i;
+                if ((fbit >> 3) < data_bytes) {
+                    l = llr(c, i);
+                    const int chb = (l < 0.0f) ? 1 : 0, db = (x.cw[c * 68 + (i >> 3)] >> (i & 7)) & 1;
+                    is = chb != db;
+                }
+            }
+            const unsigned long long mk = __ballot(is);
+            if (is) {
+                const int at = ns_all + __popcll(mk & ((1ull << lane) - 1ull));
+                x.sus[at].frame_bit = fbit;
+                x.sus[at].abs_llr = fabs_(l);
+            }
+            ns_all += __popcll(mk);
+        }
+    wave_sync();
+    if (lane == 0) sort_exact_prefix(x.sus, ns_all, 30, x.stack, suspect_lt);
+    wave_sync();
+    const int ns = ns_all < 30 ? ns_all : 30;
+    if (lane < ns) x.sd[lane] = static_cast<uint16_t>(delta(x.sus[lane].frame_bit));
+    wave_sync();
+    auto attempt = [&](int n_idx, int a, int b, int c, int d) -> bool {
+        const int idx[4] = {a, b, c, d};
+        for (int q = 0; q < n_idx; ++q) fix(x.sus[idx[q]].frame_bit);
+        if (rec_try(x)) return true;
+        for (int q = 0; q < n_idx; ++q) fix(x.sus[idx[q]].frame_bit);
+        return false;
+    };
+    const uint32_t my = (lane < ns) ? x.sd[lane] : 0u;
+    for (int a = 0; a < ns; ++a) {                            // pairs
+        unsigned long long hits = __ballot(lane > a && lane < ns && (x.sd[a] ^ my) == syn);
+        while (hits) {
+            const int b = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            if (attempt(2, a, b, 0, 0)) return true;
+        }
+    }
+    for (int a = 0; a < ns; ++a)                              // triples
+        for (int b = a + 1; b < ns; ++b) {
+            const uint32_t ab = static_cast<uint32_t>(x.sd[a] ^ x.sd[b]);
+            unsigned long long hits = __ballot(lane > b && lane < ns && (ab ^ my) == syn);
+            while (hits) {
+                const int c = __builtin_ctzll(hits);
+                hits &= hits - 1;
+                if (attempt(3, a, b, c, 0)) return true;
+            }
+        }
+    const int n4 = ns < 15 ? ns : 15;
+    for (int a = 0; a < n4; ++a)                              // quadruples of the first 15
+        for (int b = a + 1; b < n4; ++b)
+            for (int c = b + 1; c < n4; ++c) {
+                const uint32_t abc = static_cast<uint32_t>(x.sd[a] ^ x.sd[b] ^ x.sd[c]);
+                unsigned long long hits = __ballot(lane > c && lane < n4 && (abc ^ my) == syn);
+                while (hits) {
+                    const int d = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    if (attempt(4, a, b, c, d)) return true;
+                }
+            }
+    return false;
+}
+
+struct RecoveryArgs {
+    FastDecodeArgs d;
+    unsigned int* n_flagged;     // counter
+    unsigned int* flagged;       // [n_frames] frame indices needing recovery
+    unsigned int* n_list2;       // counter
+    unsigned int* list2;         // [16*n_frames] (fc << 3) | factor index
+    // host-search staging (RIA_RECOVERY_HOST=1 only)
+    uint8_t* info_c;             // [n_flagged][4*bpc]
+    float* rows_c;               // [n_flagged][4][648] decoder-order LLRs
+    uint8_t* redec_ok;           // [n_flagged][4 factors][4 cw]   (factor order of the reference: 0.75, 0.625, 0.5, 0.875)
+    uint8_t* redec_bytes;        // [n_flagged][4][4][bpc]
+};
+
+// one thread per frame: list the frames that need recovery and the (codeword, factor) decodes the
+// fallback stage (frame_v2.cpp:1836-1866) will want that the result table does not hold yet
+__global__ void recovery_list_kernel(RecoveryArgs R) {
+    int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= R.d.n_frames || !R.d.status[frame].needs_recovery) return;
+    R.flagged[atomicAdd(R.n_flagged, 1u)] = static_cast<unsigned>(frame);
+    for (int cw = 0; cw < 4; ++cw) {
+        unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
+        for (int f = 1; f <= 4; ++f)
+            if (R.d.res[fc].state[f] == 0) R.list2[atomicAdd(R.n_list2, 1u)] = (fc << 3) | static_cast<unsigned>(f);
+    }
+}
+template <class S>
+__global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned u = blockIdx.x;
+    if (u >= *R.n_list2) return;
+    FastState<S> st;
+    fast_load_tables(st, R.d.c, smem, threadIdx.x);
+    const unsigned e = R.list2[u];
+    fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
+}
+// one workgroup per flagged frame: compact copies of everything the host stage reads
+__global__ __launch_bounds__(256) void recovery_gather_kernel(RecoveryArgs R) {
+    const unsigned q = blockIdx.x;
+    if (q >= *R.n_flagged) return;
+    const unsigned frame = R.flagged[q];
+    const int bpc = R.d.c.bytes_per_cw, ib = 4 * bpc;
+    for (int i = threadIdx.x; i < ib; i += 256) R.info_c[static_cast<size_t>(q) * ib + i] = R.d.info_out[static_cast<size_t>(frame) * ib + i];
+    const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
+    for (int i = threadIdx.x; i < 4 * 648; i += 256) R.rows_c[static_cast<size_t>(q) * 4 * 648 + i] = fl[R.d.gather[i]];
+    const int forder[4] = {2, 3, 4, 1};   // reference tries 0.75, 0.625, 0.5, 0.875 (frame_v2.cpp:1837)
+    if (threadIdx.x < 16) {
+        int at = threadIdx.x >> 2, cw = threadIdx.x & 3;
+        R.redec_ok[static_cast<size_t>(q) * 16 + threadIdx.x] = R.d.res[frame * 4u + cw].state[forder[at]] == 2 ? 1 : 0;
+    }
+    for (int i = threadIdx.x; i < 16 * bpc; i += 256) {
+        int slot = i / bpc, b = i - slot * bpc, at = slot >> 2, cw = slot & 3;
+        R.redec_bytes[static_cast<size_t>(q) * 16 * bpc + i] =
+            R.d.res_bytes[(static_cast<size_t>(frame * 4u + cw) * kNumFactors + forder[at]) * bpc + b];
+    }
+}
+
+
+__host__ __device__ inline int recovery_lds_bytes(int bpc) { return 1024 + 4 * bpc * 8 * 8 + 192 * 4 + 64; }
+
+// one wave per flagged frame: stage 1, then stage 2 from the factor result table; writes the frame's
+// payload bytes and status in place
+__global__ __launch_bounds__(64) void recovery_search_kernel(RecoveryArgs R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned q = blockIdx.x;
+    if (q >= *R.n_flagged) return;
+    const unsigned frame = R.flagged[q];
+    const int lane = threadIdx.x;
+    const int bpc = R.d.c.bytes_per_cw;
+    RecCtx x;
+    x.cw = smem; x.fd = smem + 272; x.trial = smem + 544;
+    x.sd = reinterpret_cast<uint16_t*>(smem + 816);
+    x.stack = reinterpret_cast<int*>(smem + 1024);
+    x.sus = reinterpret_cast<Suspect*>(smem + 1024 + 192 * 4);
+    x.bpc = bpc; x.crc_bit = R.d.crc_bit; x.crc_init = R.d.crc_init; x.lane = lane;
+    uint8_t* info = R.d.info_out + static_cast<size_t>(frame) * 4 * bpc;
+    for (int i = lane; i < 4 * 68; i += 64) { const int c = i / 68, b = i - c * 68; x.cw[i] = (b < bpc) ? info[c * bpc + b] : 0; }
+    wave_sync();
+    const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
+    const uint16_t* gather = R.d.gather;
+    bool good = rec_search(x, [&](int c, int i) { return fl[gather[c * 648 + i]]; });
+    if (!good) {
+        // Stage 2 (frame_v2.cpp:1836-1866): factors 0.75, 0.625, 0.5, 0.875 = kFactors[2, 3, 4, 1]
+        const int forder[4] = {2, 3, 4, 1};
+        for (int at = 0; at < 4 && !good; ++at)
+            for (int c = 0; c < 4 && !good; ++c) {
+                const unsigned fc = frame * 4u + c;
+                if (R.d.res[fc].state[forder[at]] != 2) continue;
+                const uint8_t* rd = R.d.res_bytes + (static_cast<size_t>(fc) * kNumFactors + forder[at]) * bpc;
+                bool diff = false;
+                for (int b = lane; b < bpc; b += 64) diff = diff || rd[b] != x.cw[c * 68 + b];
+                if (__ballot(diff) == 0ull) continue;
+                uint8_t keep0 = 0, keep1 = 0;   // bpc <= 68 < 128: two bytes per lane
+                wave_sync();
+                if (lane < bpc) { keep0 = x.cw[c * 68 + lane]; x.cw[c * 68 + lane] = rd[lane]; }
+                if (lane + 64 < bpc) { keep1 = x.cw[c * 68 + lane + 64]; x.cw[c * 68 + lane + 64] = rd[lane + 64]; }
+                wave_sync();
+                if (rec_try(x)) { good = true; break; }
+                if (lane < bpc) x.cw[c * 68 + lane] = keep0;
+                if (lane + 64 < bpc) x.cw[c * 68 + lane + 64] = keep1;
+                wave_sync();
+            }
+    }
+    wave_sync();
+    for (int i = lane; i < 4 * bpc; i += 64) { const int c = i / bpc, b = i - c * bpc; info[i] = good ? x.cw[c * 68 + b] : 0; }
+    if (lane == 0) {
+        ria_decode_status* s = R.d.status + frame;
+        s->needs_recovery = 0;
+        s->frame_valid = good ? 1 : 0;
+        for (int c = 0; c < 4; ++c) s->cw_ok[c] = good ? 1 : 0;
+    }
+}
+
+}  // namespace ria

@@ -19,6 +19,7 @@
 #include "frame_recovery.hpp"
 #include "ldpc_kernels.hip.h"
 #include "ldpc_fast.hip.h"
+#include "recovery_kernels.hip.h"
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
 
@@ -57,7 +58,7 @@ struct ria_gpu {
     ria_decode_status* d_st_c = nullptr;
     unsigned int* p_rctl = nullptr; unsigned int* p_flagged = nullptr; uint8_t* p_info_c = nullptr; float* p_rows_c = nullptr;
     uint8_t* p_redec_ok = nullptr; uint8_t* p_redec_bytes = nullptr; ria_decode_status* p_st_c = nullptr;
-    int rec_frames = 0;
+    int rec_frames = 0, rec_host_frames = 0;
     Crc16Tables crc;
 };
 
@@ -163,32 +164,36 @@ static void parallel_for(int n, F&& f) {
     for (auto& t : th) t.join();
 }
 
-static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames) {
-    if (n_frames <= h->rec_frames) return hipSuccess;
-    for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_info_c, (void**)&h->d_rows_c,
-                     (void**)&h->d_redec_ok, (void**)&h->d_redec_bytes, (void**)&h->d_st_c}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    for (void** p : {(void**)&h->p_rctl, (void**)&h->p_flagged, (void**)&h->p_info_c, (void**)&h->p_rows_c, (void**)&h->p_redec_ok,
-                     (void**)&h->p_redec_bytes, (void**)&h->p_st_c}) { if (*p) (void)hipHostFree(*p); *p = nullptr; }
+static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames, bool host_staging) {
     const size_t n = static_cast<size_t>(n_frames), ib = h->geo.info_bytes_per_frame, bpc = h->geo.bytes_per_codeword;
     hipError_t e;
 #define A_TRY(expr) if ((e = (expr)) != hipSuccess) return e
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_info_c), n * ib));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rows_c), n * 4 * 648 * 4));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_redec_ok), n * 16));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_redec_bytes), n * 16 * bpc));
-    A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_st_c), n * sizeof(ria_decode_status)));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_rctl), 16, hipHostMallocDefault));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_flagged), n * 4, hipHostMallocDefault));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_info_c), n * ib, hipHostMallocDefault));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_rows_c), n * 4 * 648 * 4, hipHostMallocDefault));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_redec_ok), n * 16, hipHostMallocDefault));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_redec_bytes), n * 16 * bpc, hipHostMallocDefault));
-    A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_st_c), n * sizeof(ria_decode_status), hipHostMallocDefault));
+    if (n_frames > h->rec_frames) {
+        for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
+        h->rec_frames = n_frames;
+    }
+    if (host_staging && n_frames > h->rec_host_frames) {
+        for (void** p : {(void**)&h->d_info_c, (void**)&h->d_rows_c, (void**)&h->d_redec_ok, (void**)&h->d_redec_bytes, (void**)&h->d_st_c}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (void** p : {(void**)&h->p_rctl, (void**)&h->p_flagged, (void**)&h->p_info_c, (void**)&h->p_rows_c, (void**)&h->p_redec_ok,
+                         (void**)&h->p_redec_bytes, (void**)&h->p_st_c}) { if (*p) (void)hipHostFree(*p); *p = nullptr; }
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_info_c), n * ib));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rows_c), n * 4 * 648 * 4));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_redec_ok), n * 16));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_redec_bytes), n * 16 * bpc));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_st_c), n * sizeof(ria_decode_status)));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_rctl), 16, hipHostMallocDefault));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_flagged), n * 4, hipHostMallocDefault));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_info_c), n * ib, hipHostMallocDefault));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_rows_c), n * 4 * 648 * 4, hipHostMallocDefault));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_redec_ok), n * 16, hipHostMallocDefault));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_redec_bytes), n * 16 * bpc, hipHostMallocDefault));
+        A_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->p_st_c), n * sizeof(ria_decode_status), hipHostMallocDefault));
+        h->rec_host_frames = n_frames;
+    }
 #undef A_TRY
-    h->rec_frames = n_frames;
     return hipSuccess;
 }
 
@@ -209,19 +214,43 @@ __global__ void recovery_scatter_kernel(int nf, const unsigned int* __restrict__
 }
 
 // Runs after the decode kernels when RIA_DECODE_CRC_RECOVER is set (frame_v2.cpp:1564-1880).
-// The GPU lists the flagged frames, completes the min-sum-factor result table for them (the fallback
-// stage re-decodes with 0.75/0.625/0.5/0.875: the same decodes phase 0 makes) and packs the host
-// stage's inputs into pinned buffers; the byte-level CRC searches run on the host threads.
-// Synchronises the stream.
+// The GPU lists the flagged frames and completes the min-sum-factor result table for them (the fallback
+// stage re-decodes with 0.75/0.625/0.5/0.875: the same decodes phase 0 makes); then one wave per flagged
+// frame runs the CRC-guided searches (recovery_kernels.hip.h).  Nothing leaves the device and nothing
+// synchronises.  RIA_RECOVERY_HOST=1 selects the host restatement of the same searches
+// (frame_recovery.hpp) instead, which the tests use to cross-check the two implementations.
+static int run_crc_recovery_host(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s);
 static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s) {
+    const char* env = getenv("RIA_RECOVERY_HOST");   // read per call: tests flip it
+    const bool on_host = env != nullptr && env[0] == '1';
+    if (on_host) return run_crc_recovery_host(h, D, s);
+    const int n_frames = D.n_frames;
+    hipError_t e0 = ensure_recovery_ws(h, std::max(n_frames, h->cfg.max_batch), false);
+    if (e0 != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery workspace: %s", hipGetErrorString(e0));
+    RecoveryArgs R{};
+    R.d = D;
+    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1;
+    R.flagged = h->d_flagged; R.list2 = h->d_list2;
+    if (hipMemsetAsync(h->d_rctl, 0, 16, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
+    dispatch_shape(h->cfg.code_rate, [&](auto sh) {
+        using S = decltype(sh);
+        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(n_frames * 16), dim3(64), h->wave_lds, s, R);
+    });
+    hipLaunchKernelGGL(recovery_search_kernel, dim3(n_frames), dim3(64), recovery_lds_bytes(h->geo.bytes_per_codeword), s, R);
+    if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery kernel launch failed");
+    return RIA_OK;
+}
+
+static int run_crc_recovery_host(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s) {
     static const bool tdbg = getenv("RIA_DEBUG_RECOVERY") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const int n_frames = D.n_frames;
     double tA = now();
-    hipError_t e0 = ensure_recovery_ws(h, std::max(n_frames, h->cfg.max_batch));
+    hipError_t e0 = ensure_recovery_ws(h, std::max(n_frames, h->cfg.max_batch), true);
     if (e0 != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery workspace: %s", hipGetErrorString(e0));
     const int bpc = h->geo.bytes_per_codeword, ib = h->geo.info_bytes_per_frame;
-    RecoveryArgs R;
+    RecoveryArgs R{};
     R.d = D;
     R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1;
     R.flagged = h->d_flagged; R.list2 = h->d_list2;

@@ -1,0 +1,154 @@
+// ria_amd/csrc/sort_exact.hpp — libstdc++ std::sort(first, last, comp), restated so that it runs on one
+// GPU lane as well as on the host, and produces the SAME permutation as the library does.
+//
+// Why it matters: the CRC recovery of v2::decodeFixedFrame sorts its "suspect" bits with std::sort and a
+// comparator on |LLR| only (frame_v2.cpp:1717-1718).  std::sort is not stable, so the order of equal
+// keys — which decides the suspects that are tried — is whatever GCC's introsort leaves behind:
+//   __introsort_loop (median-of-3 to *first, unguarded Hoare partition, recurse right / loop left,
+//   heapsort when the depth budget 2*floor(log2 n) is spent) over ranges longer than 16, then
+//   __final_insertion_sort (guarded insertion on the first 16, unguarded linear inserts after).
+// This is the published algorithm of libstdc++ (bits/stl_algo.h, bits/stl_heap.h), not reference code.
+//
+// sort_exact_prefix() is the same algorithm restricted to what can influence positions [0, want):
+// partitions that lie entirely at or beyond `want + 16` never exchange elements with the prefix, and
+// the final insertion pass never moves an element across a partition boundary (strict comparator), so
+// the prefix comes out identical while the work drops from O(n log n) to O(n).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RIA_HD __host__ __device__
+#else
+#define RIA_HD
+#endif
+
+namespace ria {
+
+struct Suspect { int frame_bit; float abs_llr; };
+RIA_HD inline bool suspect_lt(const Suspect& a, const Suspect& b) { return a.abs_llr < b.abs_llr; }
+
+namespace sortx {
+
+template <class T> RIA_HD inline void swp(T& a, T& b) { T t = a; a = b; b = t; }
+
+// ---- bits/stl_heap.h
+template <class T, class C>
+RIA_HD inline void push_heap(T* first, int hole, int top, T value, C lt) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && lt(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+template <class T, class C>
+RIA_HD inline void adjust_heap(T* first, int hole, int len, T value, C lt) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (lt(first[child], first[child - 1])) --child;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    push_heap(first, hole, top, value, lt);
+}
+template <class T, class C>
+RIA_HD inline void heap_sort(T* first, T* last, C lt) {   // __partial_sort(first, last, last)
+    const int len = static_cast<int>(last - first);
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) {
+            T v = first[parent];
+            adjust_heap(first, parent, len, v, lt);
+            if (parent == 0) break;
+        }
+    while (last - first > 1) {
+        --last;
+        T v = *last;
+        *last = *first;
+        adjust_heap(first, 0, static_cast<int>(last - first), v, lt);
+    }
+}
+
+// ---- bits/stl_algo.h
+template <class T, class C>
+RIA_HD inline void unguarded_linear_insert(T* last, C lt) {
+    T val = *last;
+    T* next = last - 1;
+    while (lt(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+template <class T, class C>
+RIA_HD inline void insertion_sort(T* first, T* last, C lt) {
+    if (first == last) return;
+    for (T* i = first + 1; i != last; ++i) {
+        if (lt(*i, *first)) {
+            T v = *i;
+            for (T* p = i; p != first; --p) *p = *(p - 1);
+            *first = v;
+        } else {
+            unguarded_linear_insert(i, lt);
+        }
+    }
+}
+template <class T, class C>
+RIA_HD inline T* partition_pivot(T* first, T* last, C lt) {   // __unguarded_partition_pivot
+    T *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1;
+    if (lt(*a, *b)) {
+        if (lt(*b, *c)) swp(*first, *b); else if (lt(*a, *c)) swp(*first, *c); else swp(*first, *a);
+    } else {
+        if (lt(*a, *c)) swp(*first, *a); else if (lt(*b, *c)) swp(*first, *c); else swp(*first, *b);
+    }
+    T *lo = first + 1, *hi = last;
+    for (;;) {
+        while (lt(*lo, *first)) ++lo;
+        --hi;
+        while (lt(*first, *hi)) --hi;
+        if (!(lo < hi)) return lo;
+        swp(*lo, *hi);
+        ++lo;
+    }
+}
+
+}  // namespace sortx
+
+// Leaves v[0 .. min(n, want)) exactly as std::sort(v, v + n, lt) would.  `stack` holds 3 ints per pending
+// range (the recursion of __introsort_loop): 3 * 64 ints are plenty (depth <= 2*log2 n).
+// depth_budget < 0: the library's 2*floor(log2 n); tests pass 0 to force the heapsort branch.
+template <class T, class C>
+RIA_HD inline void sort_exact_prefix(T* v, int n, int want, int* stack, C lt, int depth_budget = -1) {
+    if (n <= 0) return;
+    const int limit = (want >= n) ? n : want + 16;   // positions at or beyond this never reach the prefix
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    int sp = 0;
+    stack[0] = 0; stack[1] = n; stack[2] = depth_budget < 0 ? 2 * lg : depth_budget;
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stack[3 * sp], last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        while (last - first > 16) {
+            if (first >= limit) break;
+            if (depth == 0) { sortx::heap_sort(v + first, v + last, lt); break; }
+            --depth;
+            const int cut = static_cast<int>(sortx::partition_pivot(v + first, v + last, lt) - v);
+            if (cut < limit) { stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; ++sp; }
+            last = cut;
+        }
+    }
+    const int fin = (limit < n) ? limit : n;
+    if (n > 16) {
+        sortx::insertion_sort(v, v + 16, lt);
+        for (T* i = v + 16; i != v + fin; ++i) sortx::unguarded_linear_insert(i, lt);
+    } else {
+        sortx::insertion_sort(v, v + n, lt);
+    }
+}
+
+}  // namespace ria
