@@ -214,87 +214,311 @@ inline LdpcCode build_ldpc(int rate) {  // ldpc_decoder.cpp:21-36, :65-138 (enco
 
 // ---------------------------------------------------------------- register-resident decoder tables
 // Layout the wave-per-codeword decoder (ldpc_fast.hip.h) works on.  Rows are sorted by decreasing number
-// of information edges and cut into rounds of 64 rows of EQUAL degree (a new round starts whenever the
-// degree changes, the tail lanes of a round stay idle); information columns are sorted by decreasing
-// degree, 64 per round.  The arithmetic is unaffected: variable sums still run in ascending ORIGINAL
+// of information edges and cut into rounds of 64; round r is unrolled for ne[r] = its largest degree, the
+// slots s >= nm[r] (its smallest degree) are "mixed": lanes whose row is shorter are padded there (they
+// read a zero word, their c2v word holds -FLT_MAX for good and their store goes to a dump word, so the
+// padded edge is the neutral element of min/sign without a single extra instruction).  Information
+// columns are sorted by decreasing degree, 64 per round, dv[r] = largest degree in the round; shorter
+// columns add zero words.  The arithmetic is unaffected: variable sums still run in ascending ORIGINAL
 // check order.  All addresses are BYTE offsets inside the wave's LDS region:
 //   c2v word of (round r, slot s, lane l) = 64*(row_off[r] + s) + l
-//   total of the column at sorted position q = tot_word + q;  64 words of +0.0f at zero_word.
+//   total of the column at position q     = tot_word + q
+//   zero words (read-only +0.0f)          = zero_word + lane,   dump words = dump_word + lane.
+// Which lane a row / column sits on inside its round, and which slot an edge takes inside its row, does
+// not change any result (min, xor and the per-column sums do not see it) but decides the LDS bank
+// conflicts of the two gathers (bank = word mod 32, conflicts are per half-wave): optimise_banks()
+// anneals those three choices; the decode kernels are LDS-bound and VALU-bound at once, so a conflict
+// is paid in full.
 struct CoreTables {
     int k = 0, m = 0;
-    std::vector<int> ne;               // information edges per row round
+    std::vector<int> ne, nm;           // per row round: slots unrolled, smallest row degree
     std::vector<int> dv;               // max degree per column round
-    int ts = 0, td = 0, tot_word = 0, zero_word = 0;
+    int ts = 0, td = 0, n_mixed = 0, tot_word = 0, zero_word = 0, dump_word = 0;
     std::vector<uint16_t> row_addr;    // [ts][64]
     std::vector<uint16_t> col_addr;    // [td][64]
     std::vector<uint16_t> check_at;    // [64*NR]  0xFFFF idle
     std::vector<uint16_t> col_at;      // [64*NC]  0xFFFF idle
     std::vector<uint16_t> col_pos;     // [k]
+    int conflict_cost_before = 0, conflict_cost_after = 0, conflict_floor = 0;   // sum over half-wave gathers of the worst bank multiplicity
 };
 
-inline CoreTables build_core_tables(const LdpcCode& c) {
-    CoreTables t;
-    t.k = c.k; t.m = c.m;
+struct CoreLayout {
+    int k = 0, m = 0, NR = 0, NC = 0;
+    std::vector<int> ne, nm, dv, row_off, col_off;
+    std::vector<int> check_at;                    // [64*NR] check or -1
+    std::vector<int> row_pos;                     // [m]
+    std::vector<std::vector<int>> row_cols;       // [m] information columns in slot order
+    std::vector<std::vector<int>> row_d;          // [m] for each slot: index of this edge in its column's ascending-check list
+    std::vector<int> col_at;                      // [64*NC] column or -1
+    std::vector<int> col_pos;                     // [k]
+    std::vector<std::vector<int>> col_checks;     // [k] ascending check order
+};
+
+namespace bankopt {
+// one half-wave gather: LDS passes = worst bank multiplicity (distinct words per bank); word < 0: the lane
+// reads its own zero word.  Returns kPassWeight * passes + sum of squared multiplicities: the second term
+// only breaks ties, it gives the annealer a slope on the plateaus of the max.
+constexpr int kPassWeight = 64;
+inline int half_cost(const int* word, int lane0) {
+    int cnt[32] = {0};
+    int seen[32][8];
+    int worst = 1;
+    for (int l = 0; l < 32; ++l) {
+        const int w = word[l] < 0 ? -(lane0 + l) - 1 : word[l];
+        const int b = word[l] < 0 ? (lane0 + l) & 31 : (w & 31);
+        bool dup = false;
+        for (int i = 0; i < cnt[b] && i < 8; ++i) dup = dup || seen[b][i] == w;
+        if (dup) continue;
+        if (cnt[b] < 8) seen[b][cnt[b]] = w;
+        ++cnt[b];
+        if (cnt[b] > worst) worst = cnt[b];
+    }
+    int sq = 0;
+    for (int b = 0; b < 32; ++b) sq += cnt[b] * cnt[b];
+    return kPassWeight * worst + sq;
+}
+}  // namespace bankopt
+
+struct BankOptimiser {
+    CoreLayout& L;
+    std::vector<int> g1, g2;   // cost per half-wave gather: g1[(row_off[r]+s)*2 + h], g2[(col_off[cr]+d)*2 + h]
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    explicit BankOptimiser(CoreLayout& l) : L(l) {}
+    uint32_t next() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return static_cast<uint32_t>(rng >> 33); }
+    int eval_g1(int r, int s, int h) const {
+        int word[32];
+        for (int l = 0; l < 32; ++l) {
+            const int i = L.check_at[64 * r + 32 * h + l];
+            word[l] = (i >= 0 && s < static_cast<int>(L.row_cols[i].size())) ? L.col_pos[L.row_cols[i][s]] : -1;
+        }
+        return bankopt::half_cost(word, 32 * h);
+    }
+    int eval_g2(int cr, int d, int h) const {
+        int word[32];
+        for (int l = 0; l < 32; ++l) {
+            const int c = L.col_at[64 * cr + 32 * h + l];
+            word[l] = -1;
+            if (c >= 0 && d < static_cast<int>(L.col_checks[c].size())) {
+                const int i = L.col_checks[c][d];
+                int s = 0;
+                while (L.row_cols[i][s] != c) ++s;
+                word[l] = 64 * (L.row_off[L.row_pos[i] / 64] + s) + L.row_pos[i] % 64;
+            }
+        }
+        return bankopt::half_cost(word, 32 * h);
+    }
+    int total() {
+        g1.assign(static_cast<size_t>(2) * L.row_off[L.NR], 1);
+        g2.assign(static_cast<size_t>(2) * std::max(1, L.col_off[L.NC]), 1);
+        int t = 0;
+        for (int r = 0; r < L.NR; ++r) for (int s = 0; s < L.ne[r]; ++s) for (int h = 0; h < 2; ++h) t += g1[(L.row_off[r] + s) * 2 + h] = eval_g1(r, s, h);
+        for (int cr = 0; cr < L.NC; ++cr) for (int d = 0; d < L.dv[cr]; ++d) for (int h = 0; h < 2; ++h) t += g2[(L.col_off[cr] + d) * 2 + h] = eval_g2(cr, d, h);
+        return t;
+    }
+    int floor_cost() const { return 2 * (L.row_off[L.NR] + L.col_off[L.NC]); }   // in passes
+    int passes() const {
+        int t = 0;
+        for (int v : g1) t += v / bankopt::kPassWeight;
+        for (int v : g2) t += v / bankopt::kPassWeight;
+        return t;
+    }
+    // affected gather lists (ids: g1 -> id, g2 -> id + G1N)
+    void touch_row(int i, std::vector<int>& out) const {
+        if (i < 0) return;
+        const int r = L.row_pos[i] / 64, h = (L.row_pos[i] % 64) / 32;
+        for (int s = 0; s < L.ne[r]; ++s) out.push_back((L.row_off[r] + s) * 2 + h);
+        for (size_t s = 0; s < L.row_cols[i].size(); ++s) {
+            const int c = L.row_cols[i][s], q = L.col_pos[c];
+            out.push_back(static_cast<int>(g1.size()) + (L.col_off[q / 64] + L.row_d[i][s]) * 2 + (q % 64) / 32);
+        }
+    }
+    void touch_col_pos(int q, std::vector<int>& out) const {
+        const int cr = q / 64, h = (q % 64) / 32;
+        for (int d = 0; d < L.dv[cr]; ++d) out.push_back(static_cast<int>(g1.size()) + (L.col_off[cr] + d) * 2 + h);
+        const int c = L.col_at[q];
+        if (c < 0) return;
+        for (int i : L.col_checks[c]) {
+            int s = 0;
+            while (L.row_cols[i][s] != c) ++s;
+            const int p = L.row_pos[i];
+            out.push_back((L.row_off[p / 64] + s) * 2 + (p % 64) / 32);
+        }
+    }
+    int eval_id(int id) const {
+        const int G1N = static_cast<int>(g1.size());
+        if (id < G1N) {
+            const int slot = id / 2, h = id % 2;
+            int r = 0;
+            while (L.row_off[r + 1] <= slot) ++r;
+            return eval_g1(r, slot - L.row_off[r], h);
+        }
+        const int slot = (id - G1N) / 2, h = (id - G1N) % 2;
+        int cr = 0;
+        while (L.col_off[cr + 1] <= slot) ++cr;
+        return eval_g2(cr, slot - L.col_off[cr], h);
+    }
+    int& stored(int id) { const int G1N = static_cast<int>(g1.size()); return id < G1N ? g1[id] : g2[id - G1N]; }
+
+    void run(int moves) {
+        int cur = total();
+        const int G1N = static_cast<int>(g1.size());
+        (void)G1N;
+        std::vector<int> ids, newc;
+        for (int it = 0; it < moves; ++it) {
+            const uint32_t kind = next() % 10;
+            ids.clear();
+            // --- propose
+            int a0 = -1, a1 = -1, i0 = -1, s0 = 0, s1 = 0;
+            if (kind < 4) {            // swap the lanes of two rows (or a row and an idle lane) of one round
+                const int r = static_cast<int>(next() % L.NR);
+                a0 = 64 * r + static_cast<int>(next() % 64); a1 = 64 * r + static_cast<int>(next() % 64);
+                if (a0 == a1 || (L.check_at[a0] < 0 && L.check_at[a1] < 0)) continue;
+                touch_row(L.check_at[a0], ids); touch_row(L.check_at[a1], ids);
+                auto apply = [&]() {
+                    std::swap(L.check_at[a0], L.check_at[a1]);
+                    if (L.check_at[a0] >= 0) L.row_pos[L.check_at[a0]] = a0;
+                    if (L.check_at[a1] >= 0) L.row_pos[L.check_at[a1]] = a1;
+                };
+                apply();
+                touch_row(L.check_at[a0], ids); touch_row(L.check_at[a1], ids);
+                if (!accept(ids, newc, cur, it, moves)) apply();
+            } else if (kind < 8) {     // swap the positions of two columns (degree must fit the round)
+                a0 = static_cast<int>(next() % (64 * L.NC)); a1 = static_cast<int>(next() % (64 * L.NC));
+                const int c0 = L.col_at[a0], c1 = L.col_at[a1];
+                if (a0 == a1 || (c0 < 0 && c1 < 0)) continue;
+                const int d0 = c0 < 0 ? 0 : static_cast<int>(L.col_checks[c0].size()), d1 = c1 < 0 ? 0 : static_cast<int>(L.col_checks[c1].size());
+                if (d0 > L.dv[a1 / 64] || d1 > L.dv[a0 / 64]) continue;
+                touch_col_pos(a0, ids); touch_col_pos(a1, ids);
+                auto apply = [&]() {
+                    std::swap(L.col_at[a0], L.col_at[a1]);
+                    if (L.col_at[a0] >= 0) L.col_pos[L.col_at[a0]] = a0;
+                    if (L.col_at[a1] >= 0) L.col_pos[L.col_at[a1]] = a1;
+                };
+                apply();
+                touch_col_pos(a0, ids); touch_col_pos(a1, ids);
+                if (!accept(ids, newc, cur, it, moves)) apply();
+            } else {                   // swap two slots of one row
+                i0 = static_cast<int>(next() % L.m);
+                const int deg = static_cast<int>(L.row_cols[i0].size());
+                if (deg < 2) continue;
+                s0 = static_cast<int>(next() % deg); s1 = static_cast<int>(next() % deg);
+                if (s0 == s1) continue;
+                const int r = L.row_pos[i0] / 64, h = (L.row_pos[i0] % 64) / 32;
+                ids.push_back((L.row_off[r] + s0) * 2 + h); ids.push_back((L.row_off[r] + s1) * 2 + h);
+                auto apply = [&]() { std::swap(L.row_cols[i0][s0], L.row_cols[i0][s1]); std::swap(L.row_d[i0][s0], L.row_d[i0][s1]); };
+                apply();
+                if (!accept(ids, newc, cur, it, moves)) apply();
+            }
+        }
+    }
+    // evaluates the touched gathers in the (already modified) layout; keeps the move if it does not
+    // raise the cost (plus a little early uphill tolerance).  Updates `cur` and the stored costs on accept.
+    bool accept(std::vector<int>& ids, std::vector<int>& newc, int& cur, int it, int moves) {
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        newc.resize(ids.size());
+        int before = 0, after = 0;
+        for (size_t q = 0; q < ids.size(); ++q) { before += stored(ids[q]); after += newc[q] = eval_id(ids[q]); }
+        const int delta = after - before;
+        const bool early = it < moves / 2;
+        const bool ok = delta <= 0 || (early && delta <= 4 && next() % 16 == 0);
+        if (!ok) return false;
+        for (size_t q = 0; q < ids.size(); ++q) stored(ids[q]) = newc[q];
+        cur += delta;
+        return true;
+    }
+};
+
+inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120000) {
+    CoreLayout L;
+    L.k = c.k; L.m = c.m;
     const int k = c.k, m = c.m;
     auto info_deg = [&](int i) { return static_cast<int>(c.rows[i].size()) - 1; };  // last edge: identity column k+i
-    std::vector<uint16_t> rows(m);
-    for (int i = 0; i < m; ++i) rows[i] = static_cast<uint16_t>(i);
-    std::stable_sort(rows.begin(), rows.end(), [&](uint16_t a, uint16_t b) { return info_deg(a) > info_deg(b); });
-    std::vector<int> pos(m);   // check -> position 64*round + lane
-    for (int i = 0; i < m;) {
-        const int d = info_deg(rows[i]);
-        int j = i;
-        while (j < m && info_deg(rows[j]) == d) ++j;
-        for (int b = i; b < j; b += 64) {
-            const int r = static_cast<int>(t.ne.size());
-            t.ne.push_back(d);
-            t.check_at.resize(static_cast<size_t>(64) * (r + 1), 0xFFFF);
-            for (int l = 0; l < 64 && b + l < j; ++l) { t.check_at[64 * r + l] = rows[b + l]; pos[rows[b + l]] = 64 * r + l; }
+    std::vector<int> rows(m);
+    for (int i = 0; i < m; ++i) rows[i] = i;
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return info_deg(a) > info_deg(b); });
+    L.NR = (m + 63) / 64;
+    L.check_at.assign(static_cast<size_t>(64) * L.NR, -1);
+    L.row_pos.assign(m, 0);
+    L.ne.assign(L.NR, 0); L.nm.assign(L.NR, 99);
+    for (int p = 0; p < m; ++p) {
+        L.check_at[p] = rows[p]; L.row_pos[rows[p]] = p;
+        L.ne[p / 64] = std::max(L.ne[p / 64], info_deg(rows[p]));
+        L.nm[p / 64] = std::min(L.nm[p / 64], info_deg(rows[p]));
+    }
+    L.row_off.assign(L.NR + 1, 0);
+    for (int r = 0; r < L.NR; ++r) L.row_off[r + 1] = L.row_off[r] + L.ne[r];
+    L.row_cols.resize(m); L.row_d.resize(m); L.col_checks.resize(k);
+    for (int i = 0; i < m; ++i) {   // ascending original check index
+        L.row_cols[i].assign(c.rows[i].begin(), c.rows[i].end() - 1);
+        L.row_d[i].resize(L.row_cols[i].size());
+        for (size_t s = 0; s < L.row_cols[i].size(); ++s) {
+            L.row_d[i][s] = static_cast<int>(L.col_checks[L.row_cols[i][s]].size());
+            L.col_checks[L.row_cols[i][s]].push_back(i);
         }
-        i = j;
     }
-    const int NR = static_cast<int>(t.ne.size());
-    std::vector<int> row_off(NR + 1, 0);
-    for (int r = 0; r < NR; ++r) row_off[r + 1] = row_off[r] + t.ne[r];
-    t.ts = row_off[NR];
-    // columns: c2v word list in ascending original check order
-    std::vector<std::vector<uint16_t>> cols(k);
-    for (int i = 0; i < m; ++i) {
-        const auto& row = c.rows[i];
-        const int r = pos[i] / 64, l = pos[i] % 64;
-        for (size_t s = 0; s + 1 < row.size(); ++s) cols[row[s]].push_back(static_cast<uint16_t>(64 * (row_off[r] + static_cast<int>(s)) + l));
-    }
-    std::vector<uint16_t> order(k);
-    for (int j = 0; j < k; ++j) order[j] = static_cast<uint16_t>(j);
-    std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return cols[a].size() > cols[b].size(); });
-    const int NC = (k + 63) / 64;
-    t.col_at.assign(static_cast<size_t>(64) * NC, 0xFFFF);
-    t.col_pos.assign(k, 0);
-    t.dv.assign(NC, 0);
+    std::vector<int> order(k);
+    for (int j = 0; j < k; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return L.col_checks[a].size() > L.col_checks[b].size(); });
+    L.NC = (k + 63) / 64;
+    L.col_at.assign(static_cast<size_t>(64) * L.NC, -1);
+    L.col_pos.assign(k, 0);
+    L.dv.assign(L.NC, 0);
     for (int q = 0; q < k; ++q) {
-        t.col_at[q] = order[q];
-        t.col_pos[order[q]] = static_cast<uint16_t>(q);
-        t.dv[q / 64] = std::max(t.dv[q / 64], static_cast<int>(cols[order[q]].size()));
+        L.col_at[q] = order[q]; L.col_pos[order[q]] = q;
+        L.dv[q / 64] = std::max(L.dv[q / 64], static_cast<int>(L.col_checks[order[q]].size()));
     }
-    std::vector<int> col_off(NC + 1, 0);
-    for (int r = 0; r < NC; ++r) col_off[r + 1] = col_off[r] + t.dv[r];
-    t.td = col_off[NC];
+    L.col_off.assign(L.NC + 1, 0);
+    for (int r = 0; r < L.NC; ++r) L.col_off[r + 1] = L.col_off[r] + L.dv[r];
+
+    CoreTables t;
+    t.k = k; t.m = m;
+    {
+        BankOptimiser opt(L);
+        (void)opt.total();
+        t.conflict_cost_before = opt.passes();
+        t.conflict_floor = opt.floor_cost();
+        if (optimiser_moves > 0) opt.run(optimiser_moves);
+        (void)opt.total();
+        t.conflict_cost_after = opt.passes();
+    }
+    t.ne = L.ne; t.nm = L.nm; t.dv = L.dv;
+    t.ts = L.row_off[L.NR]; t.td = L.col_off[L.NC];
+    for (int r = 0; r < L.NR; ++r) t.n_mixed += L.ne[r] - L.nm[r];
     t.tot_word = 64 * t.ts;
-    t.zero_word = t.tot_word + 64 * NC;
-    const uint16_t zero_addr = static_cast<uint16_t>(4 * t.zero_word);
-    t.row_addr.assign(static_cast<size_t>(64) * std::max(1, t.ts), zero_addr);
-    for (int r = 0; r < NR; ++r)
+    t.zero_word = t.tot_word + 64 * L.NC;
+    t.dump_word = t.zero_word + 64;
+    t.check_at.assign(L.check_at.size(), 0xFFFF);
+    for (size_t p = 0; p < L.check_at.size(); ++p) if (L.check_at[p] >= 0) t.check_at[p] = static_cast<uint16_t>(L.check_at[p]);
+    t.col_at.assign(L.col_at.size(), 0xFFFF);
+    for (size_t q = 0; q < L.col_at.size(); ++q) if (L.col_at[q] >= 0) t.col_at[q] = static_cast<uint16_t>(L.col_at[q]);
+    t.col_pos.resize(k);
+    for (int j = 0; j < k; ++j) t.col_pos[j] = static_cast<uint16_t>(L.col_pos[j]);
+    t.row_addr.assign(static_cast<size_t>(64) * std::max(1, t.ts), 0);
+    for (int r = 0; r < L.NR; ++r)
         for (int l = 0; l < 64; ++l) {
-            const uint16_t i = t.check_at[64 * r + l];
-            if (i == 0xFFFF) continue;
-            for (int s = 0; s < t.ne[r]; ++s)
-                t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l] = static_cast<uint16_t>(4 * (t.tot_word + t.col_pos[c.rows[i][s]]));
+            const int i = L.check_at[64 * r + l];
+            for (int s = 0; s < L.ne[r]; ++s) {
+                int w = t.zero_word + l;
+                if (i >= 0 && s < static_cast<int>(L.row_cols[i].size())) w = t.tot_word + L.col_pos[L.row_cols[i][s]];
+                t.row_addr[static_cast<size_t>(64) * (L.row_off[r] + s) + l] = static_cast<uint16_t>(4 * w);
+            }
         }
-    t.col_addr.assign(static_cast<size_t>(64) * std::max(1, t.td), zero_addr);
-    for (int q = 0; q < k; ++q) {
-        const auto& v = cols[order[q]];
-        for (size_t d = 0; d < v.size(); ++d) t.col_addr[static_cast<size_t>(64) * (col_off[q / 64] + static_cast<int>(d)) + q % 64] = static_cast<uint16_t>(4 * v[d]);
-    }
+    t.col_addr.assign(static_cast<size_t>(64) * std::max(1, t.td), 0);
+    for (int cr = 0; cr < L.NC; ++cr)
+        for (int l = 0; l < 64; ++l) {
+            const int cc = L.col_at[64 * cr + l];
+            for (int d = 0; d < L.dv[cr]; ++d) {
+                int w = t.zero_word + l;
+                if (cc >= 0 && d < static_cast<int>(L.col_checks[cc].size())) {
+                    const int i = L.col_checks[cc][d];
+                    int s = 0;
+                    while (L.row_cols[i][s] != cc) ++s;
+                    w = 64 * (L.row_off[L.row_pos[i] / 64] + s) + L.row_pos[i] % 64;
+                }
+                t.col_addr[static_cast<size_t>(64) * (L.col_off[cr] + d) + l] = static_cast<uint16_t>(4 * w);
+            }
+        }
     return t;
 }
 

@@ -32,38 +32,45 @@
 namespace ria {
 
 // ---- compile-time shape of a code ------------------------------------------------------------------
-// NR row rounds with ne(r) information edges each (rows sorted by decreasing degree, a new round starts
-// whenever the degree changes), NC information-column rounds with dv(r) = largest degree in the round
-// (columns sorted by decreasing degree).  host_tables.hpp derives the same structure from H and
-// ria_gpu_create refuses a code whose structure differs.
+// NR row rounds of 64 rows (rows sorted by decreasing degree): round r is unrolled for ne(r) = its largest
+// number of information edges, nm(r) = its smallest; slots s >= nm(r) are "mixed" (some lanes padded).
+// NC information-column rounds with dv(r) = largest degree in the round (columns sorted by decreasing
+// degree).  host_tables.hpp derives the same structure from H and ria_gpu_create refuses a code whose
+// structure differs.
 struct ShapeR12 {   // R1/2: m = 324, k = 324
-    static constexpr int NR = 7, NC = 6;
-    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 2, 1}; return t[r]; }
+    static constexpr int NR = 6, NC = 6;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 2, 1}; return t[r]; }
+    static constexpr int nm(int r) { constexpr int t[NR] = {6, 5, 4, 2, 1, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {5, 4, 4, 4, 4, 4}; return t[r]; }
 };
 struct ShapeR13 {   // R1/3 entry of the rate table: same (324,324) parameters, H seeded differently
-    static constexpr int NR = 8, NC = 6;
-    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 3, 2, 1}; return t[r]; }
+    static constexpr int NR = 6, NC = 6;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 3, 3, 1}; return t[r]; }
+    static constexpr int nm(int r) { constexpr int t[NR] = {6, 5, 3, 3, 1, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {6, 4, 4, 4, 4, 4}; return t[r]; }
 };
 struct ShapeR14 {   // m = 486, k = 162
-    static constexpr int NR = 11, NC = 3;
-    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1}; return t[r]; }
+    static constexpr int NR = 8, NC = 3;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 5, 4, 3, 2, 2}; return t[r]; }
+    static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 2, 2, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {13, 12, 12}; return t[r]; }
 };
 struct ShapeR23 {   // m = 216, k = 432
-    static constexpr int NR = 5, NC = 7;
-    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6, 6, 4}; return t[r]; }
+    static constexpr int NR = 4, NC = 7;
+    static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6, 6}; return t[r]; }
+    static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6, 4}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 3}; return t[r]; }
 };
 struct ShapeR34 {   // m = 162, k = 486 (161 information columns have no edge at all)
     static constexpr int NR = 3, NC = 8;
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
+    static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 0, 0}; return t[r]; }
 };
 struct ShapeR56 {   // m = 108, k = 540
     static constexpr int NR = 2, NC = 9;
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
+    static constexpr int nm(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 0, 0, 0, 0, 0}; return t[r]; }
 };
 
@@ -71,11 +78,14 @@ template <class S>
 struct ShapeInfo {
     static constexpr int row_off(int r) { int t = 0; for (int i = 0; i < r; ++i) t += S::ne(i); return t; }   // x 64 words
     static constexpr int col_off(int r) { int t = 0; for (int i = 0; i < r; ++i) t += S::dv(i); return t; }
+    static constexpr int mix_off(int r) { int t = 0; for (int i = 0; i < r; ++i) t += S::ne(i) - S::nm(i); return t; }
     static constexpr int TS = row_off(S::NR);          // c2v slot groups (64 words each)
     static constexpr int TD = col_off(S::NC);          // column gather addresses per lane
+    static constexpr int TM = mix_off(S::NR);          // mixed slots (per-lane store addresses)
     static constexpr int tot_word = 64 * TS;           // column totals [64*NC]
-    static constexpr int zero_word = tot_word + 64 * S::NC;   // 64 words of +0.0f
-    static constexpr int words = zero_word + 64;
+    static constexpr int zero_word = tot_word + 64 * S::NC;   // 64 words of +0.0f (one per lane)
+    static constexpr int dump_word = zero_word + 64;          // 64 write-only words (one per lane)
+    static constexpr int words = dump_word + 64;
     // the same region doubles as mt19937 state + 648 normals during the retry cascade (>= 1296 words)
     static constexpr int lds_bytes = ((words < 1296 ? 1296 : words) * 4 + 15) & ~15;
 };
@@ -103,6 +113,7 @@ struct FastState {
     using I = ShapeInfo<S>;
     uint32_t rv[I::TS];            // gather addresses of the check pass
     uint32_t cs[I::TD > 0 ? I::TD : 1];   // gather addresses of the column pass
+    uint32_t sa[I::TM > 0 ? I::TM : 1];   // store addresses of the mixed slots (dump word on padded lanes)
     float li[S::NC];               // information-column LLRs (sorted position q = lane + 64 r)
     float lp[S::NR];               // identity-column LLRs (row position p = lane + 64 r)
     float pv[S::NR];               // v2c of the identity edges
@@ -126,6 +137,18 @@ __device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, con
     for (int i = 0; i < I::TS; ++i) { uint32_t a = base + c.row_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.rv[i] = a; }
 #pragma unroll
     for (int i = 0; i < I::TD; ++i) { uint32_t a = base + c.col_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.cs[i] = a; }
+    // mixed slots: a lane whose row has no edge there (its gather address points at the zero words)
+    // stores to its dump word, so that the -FLT_MAX it finds in the c2v word is never overwritten
+    static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
+        constexpr int r = decltype(R_)::value;
+#pragma unroll
+        for (int s = S::nm(r); s < S::ne(r); ++s) {
+            const bool padded = c.row_addr[(I::row_off(r) + s) * 64 + lane] >= 4u * I::zero_word;
+            uint32_t a = base + 4u * (padded ? I::dump_word + lane : 64 * (I::row_off(r) + s) + lane);
+            asm volatile("" : "+v"(a));
+            st.sa[I::mix_off(r) + s - S::nm(r)] = a;
+        }
+    });
 }
 
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
@@ -165,9 +188,19 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
     const uint32_t lane4 = lds_addr(lds) + static_cast<uint32_t>(lane) * 4u;
     const uint32_t kInfBits = 0x7f7fffffu;  // FLT_MAX, the reference's initial min_abs
     const uint32_t kAbs = 0x7fffffffu;
-    // c2v := 0, tot := channel LLR of the information columns, zero words
+    // c2v := 0 (-FLT_MAX on the padded lanes of mixed slots: |0 - c2v| is then the neutral element of the
+    // row minimum, FLT_MAX in iteration 0 and 50 = the clamp afterwards, with a positive sign),
+    // tot := channel LLR of the information columns, zero words
+    static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
+        constexpr int r = decltype(R_)::value;
 #pragma unroll
-    for (int i = 0; i < I::TS; ++i) lds_sf(lane4 + 256u * i, 0.0f);
+        for (int s = 0; s < S::ne(r); ++s) {
+            const uint32_t own = lane4 + 256u * (I::row_off(r) + s);
+            float v0 = 0.0f;
+            if (s >= S::nm(r)) v0 = (st.sa[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)] != own) ? -3.402823466e+38f : 0.0f;
+            lds_sf(own, v0);
+        }
+    });
 #pragma unroll
     for (int r = 0; r < S::NC; ++r) lds_sf(lane4 + 4u * (I::tot_word + 64 * r), st.li[r]);
     lds_sf(lane4 + 4u * I::zero_word, 0.0f);
@@ -211,7 +244,8 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             for (int s = 0; s < NE; ++s) {
                 // min over the OTHER edges: min2 if this edge holds the minimum (ties: min2 == min1)
                 const uint32_t mn = (ab[s] == min1) ? m2f : m1f;
-                lds_sf(lane4 + 256u * (off + s), u2f(bfi(kAbs, mn, sgn ^ vb[s])));
+                const uint32_t dst = (s >= S::nm(r)) ? st.sa[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)] : lane4 + 256u * (off + s);
+                lds_sf(dst, u2f(bfi(kAbs, mn, sgn ^ vb[s])));
             }
             {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
                 const uint32_t mn = ((xp & kAbs) == min1) ? m2f : m1f;

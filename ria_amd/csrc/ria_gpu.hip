@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <string>
@@ -118,9 +120,9 @@ static bool shape_fits(int rate, const CoreTables& t, int* wave_lds) {
         using S = decltype(s);
         using I = ShapeInfo<S>;
         ok = static_cast<int>(t.ne.size()) == S::NR && static_cast<int>(t.dv.size()) == S::NC;
-        for (int r = 0; ok && r < S::NR; ++r) ok = t.ne[r] == S::ne(r);
+        for (int r = 0; ok && r < S::NR; ++r) ok = t.ne[r] == S::ne(r) && t.nm[r] == S::nm(r);
         for (int r = 0; ok && r < S::NC; ++r) ok = t.dv[r] == S::dv(r);
-        ok = ok && t.ts == I::TS && t.td == I::TD && t.tot_word == I::tot_word && t.zero_word == I::zero_word && 4 * I::words <= 65536;
+        ok = ok && t.ts == I::TS && t.td == I::TD && t.tot_word == I::tot_word && t.zero_word == I::zero_word && t.dump_word == I::dump_word && t.n_mixed == I::TM && 4 * I::words <= 65536;
         *wave_lds = I::lds_bytes;
     });
     return ok;
@@ -428,7 +430,16 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_llr_ws),
                          static_cast<size_t>(h->cfg.max_batch) * g.llrs_per_frame * sizeof(float)));
 
-    h->ftab = build_core_tables(h->code);
+    {   // the lane/slot assignment is annealed for LDS bank conflicts (host_tables.hpp): once per rate and process
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, CoreTables> cache;
+        const int moves = getenv("RIA_BANKOPT_MOVES") ? atoi(getenv("RIA_BANKOPT_MOVES")) : 60000;
+        std::lock_guard<std::mutex> lock(mu);
+        auto key = std::make_pair(static_cast<int>(cfg->code_rate), moves);
+        auto it = cache.find(key);
+        if (it == cache.end()) it = cache.emplace(key, build_core_tables(h->code, moves)).first;
+        h->ftab = it->second;
+    }
     CREATE_TRY(upload(&h->d_f_row_addr, h->ftab.row_addr));
     CREATE_TRY(upload(&h->d_f_col_addr, h->ftab.col_addr));
     CREATE_TRY(upload(&h->d_f_check_at, h->ftab.check_at));
