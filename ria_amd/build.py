@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libria_gpu.so")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-               "-fPIC", "-shared", "-std=c++17"]
+               "-fPIC", "-shared", "-std=c++17", "-Wno-inline-asm"]
 
 
 def _sources():

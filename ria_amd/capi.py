@@ -65,6 +65,7 @@ def load(build_if_needed=True):
     # and device pointers / streams from torch are valid inside the library.
     import torch  # noqa: F401
     path = _build.build() if build_if_needed else _build.LIB
+    path = os.environ.get("RIA_GPU_LIB", path)   # developer A/B switch: an alternative build of the same sources
     if not os.path.exists(path):
         raise RuntimeError("libria_gpu.so is missing: run `python -m ria_amd.build`")
     L = C.CDLL(path)

@@ -108,12 +108,27 @@ struct FastCode {
     const uint16_t* col_pos;    // [k]       sorted position of information column j
 };
 
+// Build-time experiments (measured on MI355X, C3 workload, decode kernels per 25k frames):
+//   kCvRegs   keep the row's own previous c2v in VGPRs instead of re-reading its LDS words: -24 LDS reads per
+//             iteration, +24 VGPRs -> the cascade kernel drops to 2 waves/SIMD: 20.4 -> 22.4 ms.  Off.
+//   kAddTid   ds_write_addtid_b32 for the lane-linear stores (M0 + offset + 4*lane, no address VGPR, half the
+//             store-path cycles): measured slower here (22.4 -> 23.4 ms with kCvRegs).  Off.
+#ifndef RIA_CV_REGS
+#define RIA_CV_REGS 0
+#endif
+#ifndef RIA_ADDTID
+#define RIA_ADDTID 0
+#endif
+constexpr bool kCvRegs = RIA_CV_REGS != 0;
+constexpr bool kAddTid = RIA_ADDTID != 0;
+
 template <class S>
 struct FastState {
     using I = ShapeInfo<S>;
     uint32_t rv[I::TS];            // gather addresses of the check pass
     uint32_t cs[I::TD > 0 ? I::TD : 1];   // gather addresses of the column pass
-    uint32_t sa[I::TM > 0 ? I::TM : 1];   // store addresses of the mixed slots (dump word on padded lanes)
+    uint32_t keep[I::TM > 0 ? I::TM : 1]; // mixed slots: all ones on lanes that own an edge there, 0 on padded lanes
+    float cv[kCvRegs ? I::TS : 1]; // (kCvRegs) c2v of the row's own edges as written in the previous iteration
     float li[S::NC];               // information-column LLRs (sorted position q = lane + 64 r)
     float lp[S::NR];               // identity-column LLRs (row position p = lane + 64 r)
     float pv[S::NR];               // v2c of the identity edges
@@ -125,8 +140,8 @@ using lds_float_ptr = __attribute__((address_space(3))) float*;
 __device__ __forceinline__ uint32_t lds_addr(const unsigned char* p) {
     return static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const unsigned char*)p));
 }
-__device__ __forceinline__ float lds_f(uint32_t a) { return *(lds_float_ptr)a; }
-__device__ __forceinline__ void lds_sf(uint32_t a, float v) { *(lds_float_ptr)a = v; }
+__device__ __forceinline__ float lds_f(uint32_t a) { return *(lds_float_ptr)(uintptr_t)a; }
+__device__ __forceinline__ void lds_sf(uint32_t a, float v) { *(lds_float_ptr)(uintptr_t)a = v; }
 // (the wave's LDS region starts at `lds`; absolute LDS addresses, one full VGPR each — kept opaque so
 // that the compiler does not re-pack them into 16-bit halves and pay an unpack per access)
 template <class S>
@@ -137,23 +152,47 @@ __device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, con
     for (int i = 0; i < I::TS; ++i) { uint32_t a = base + c.row_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.rv[i] = a; }
 #pragma unroll
     for (int i = 0; i < I::TD; ++i) { uint32_t a = base + c.col_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.cs[i] = a; }
-    // mixed slots: a lane whose row has no edge there (its gather address points at the zero words)
-    // stores to its dump word, so that the -FLT_MAX it finds in the c2v word is never overwritten
+    // mixed slots: a lane whose row has no edge there (its gather address points at the zero words) keeps
+    // -FLT_MAX as that edge's "previous c2v" for good: |0 - c2v| is then the neutral element of the row
+    // minimum (FLT_MAX in iteration 0, 50 = the clamp afterwards) with a positive sign
     static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
         constexpr int r = decltype(R_)::value;
 #pragma unroll
         for (int s = S::nm(r); s < S::ne(r); ++s) {
-            const bool padded = c.row_addr[(I::row_off(r) + s) * 64 + lane] >= 4u * I::zero_word;
-            uint32_t a = base + 4u * (padded ? I::dump_word + lane : 64 * (I::row_off(r) + s) + lane);
-            asm volatile("" : "+v"(a));
-            st.sa[I::mix_off(r) + s - S::nm(r)] = a;
+            uint32_t k = (c.row_addr[(I::row_off(r) + s) * 64 + lane] >= 4u * I::zero_word) ? 0u : 0xffffffffu;
+            asm volatile("" : "+v"(k));
+            st.keep[I::mix_off(r) + s - S::nm(r)] = k;
         }
     });
 }
 
+// store to LDS word (base/4 + OFF/4 + lane): ds_write_addtid_b32 takes its address from M0 + offset + 4*lane, needs
+// no address VGPR and moves half the dwords of ds_write_b32 to the LDS (2 instead of 4 cycles per wave-store).
+// M0 is (re)loaded at every use: the compiler treats it as a scratch register of its own.
+template <int OFF>
+__device__ __forceinline__ void lds_store_tid(uint32_t base, float v) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+    if constexpr (!kAddTid) {
+        *(lds_float_ptr)(uintptr_t)(base + static_cast<uint32_t>(threadIdx.x) * 4u + OFF) = v;
+        return;
+    }
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(v), "s"(base), "n"(OFF) : "memory", "m0");
+}
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// med3(|x|, b, c) and min(|x|, b) with the absolute value as a source modifier (the compiler would
+// materialise |x| with a v_and first); operands are finite, so IEEE-mode sNaN quieting never triggers
+__device__ __forceinline__ float med3_abs(float x, float b, float c) {
+    float d;
+    asm("v_med3_f32 %0, |%1|, %2, %3" : "=v"(d) : "v"(x), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float min_abs(float x, float b) {
+    float d;
+    asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(d) : "v"(x), "v"(b));
     return d;
 }
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {   // (mask & a) | (~mask & b)
@@ -186,19 +225,17 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
                                   float factor, int max_iter, int lane, bool* ok) {
     using I = ShapeInfo<S>;
     const uint32_t lane4 = lds_addr(lds) + static_cast<uint32_t>(lane) * 4u;
-    const uint32_t kInfBits = 0x7f7fffffu;  // FLT_MAX, the reference's initial min_abs
-    const uint32_t kAbs = 0x7fffffffu;
-    // c2v := 0 (-FLT_MAX on the padded lanes of mixed slots: |0 - c2v| is then the neutral element of the
-    // row minimum, FLT_MAX in iteration 0 and 50 = the clamp afterwards, with a positive sign),
-    // tot := channel LLR of the information columns, zero words
+    const uint32_t kAbs = 0x7fffffffu, kSign = 0x80000000u, kNegMax = 0xff7fffffu;   // -FLT_MAX
+    const uint32_t m0base = lds_addr(lds);
+    // previous c2v := 0 (-FLT_MAX on the padded lanes of mixed slots), tot := channel LLR of the
+    // information columns, zero words
     static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
         constexpr int r = decltype(R_)::value;
 #pragma unroll
         for (int s = 0; s < S::ne(r); ++s) {
-            const uint32_t own = lane4 + 256u * (I::row_off(r) + s);
-            float v0 = 0.0f;
-            if (s >= S::nm(r)) v0 = (st.sa[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)] != own) ? -3.402823466e+38f : 0.0f;
-            lds_sf(own, v0);
+            const float v0 = (s >= S::nm(r)) ? u2f(bfi(st.keep[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)], 0u, kNegMax)) : 0.0f;
+            if constexpr (kCvRegs) st.cv[I::row_off(r) + s] = v0;
+            else lds_sf(lane4 + 256u * (I::row_off(r) + s), v0);
         }
     });
 #pragma unroll
@@ -220,36 +257,50 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
                 t[s] = lds_f(st.rv[off + s]);
-                cold[s] = lds_f(lane4 + 256u * (off + s));
+                if constexpr (kCvRegs) cold[s] = st.cv[off + s];
+                else cold[s] = lds_f(lane4 + 256u * (off + s));
             }
-            const uint32_t xp = f2u(st.pv[r]);            // identity edge: the last edge of the row
+            // |x| rides on the float source modifiers (free), min1/min2 are v_med3_f32: med3(a, b, -inf) =
+            // min(a, b) without the sNaN quieting v_min_f32 would need.  Everything here is finite.
+            const float pvr = st.pv[r];                   // identity edge: the last edge of the row
             uint32_t par = f2u(st.pt[r]);
-            uint32_t sgn = xp, min1 = xp & kAbs, min2 = kInfBits;
-            uint32_t vb[NE], ab[NE];
+            uint32_t sgn = f2u(pvr);
+            float min1 = __builtin_fabsf(pvr), min2 = 3.402823466e+38f;   // FLT_MAX, the reference's initial min_abs
+            float v[NE];
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
-                float v = t[s] - cold[s];
-                v = __builtin_amdgcn_fmed3f(v, lo, hi);
-                par ^= f2u(t[s]);
-                vb[s] = f2u(v);
-                sgn ^= vb[s];
-                ab[s] = vb[s] & kAbs;
-                min2 = med3u(ab[s], min1, min2);
-                min1 = min(ab[s], min1);
+                v[s] = __builtin_amdgcn_fmed3f(t[s] - cold[s], lo, hi);
+                min2 = med3_abs(v[s], min1, min2);
+                min1 = min_abs(v[s], min1);
+            }
+#pragma unroll
+            for (int s = 0; s < NE; s += 2) {             // parity of the hard bits / product of the signs: xor3
+                if (s + 1 < NE) {
+                    par = __builtin_amdgcn_bitop3_b32(par, f2u(t[s]), f2u(t[s + 1]), 0x96);
+                    sgn = __builtin_amdgcn_bitop3_b32(sgn, f2u(v[s]), f2u(v[s + 1]), 0x96);
+                } else {
+                    par ^= f2u(t[s]);
+                    sgn ^= f2u(v[s]);
+                }
             }
             syn |= par;
-            // (sign * min_abs) * factor == sign * (min_abs * factor): scale the two candidates once per row
-            const uint32_t m1f = f2u(u2f(min1) * factor), m2f = f2u(u2f(min2) * factor);
-#pragma unroll
-            for (int s = 0; s < NE; ++s) {
+            // (sign * min_abs) * factor == sign * (min_abs * factor): scale the two candidates once per row and
+            // give them the row's sign product; an edge then removes its own sign: c2v = cand ^ (v & signbit),
+            // one v_bitop3 (0x78: S0 ^ (S1 & S2))
+            const uint32_t m1s = bfi(kAbs, f2u(min1 * factor), sgn), m2s = bfi(kAbs, f2u(min2 * factor), sgn);
+            static_for<0, NE>([&](auto S_) __attribute__((always_inline)) {
+                constexpr int s = decltype(S_)::value;
                 // min over the OTHER edges: min2 if this edge holds the minimum (ties: min2 == min1)
-                const uint32_t mn = (ab[s] == min1) ? m2f : m1f;
-                const uint32_t dst = (s >= S::nm(r)) ? st.sa[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)] : lane4 + 256u * (off + s);
-                lds_sf(dst, u2f(bfi(kAbs, mn, sgn ^ vb[s])));
-            }
+                const uint32_t mn = (__builtin_fabsf(v[s]) == min1) ? m2s : m1s;
+                uint32_t out = __builtin_amdgcn_bitop3_b32(mn, f2u(v[s]), kSign, 0x78);
+                // padded lanes of a mixed slot keep -FLT_MAX as this edge's c2v
+                if constexpr (s >= S::nm(r)) out = bfi(st.keep[I::mix_off(r) + s - S::nm(r)], out, kNegMax);
+                lds_store_tid<256 * (off + s)>(m0base, u2f(out));
+                if constexpr (kCvRegs) st.cv[off + s] = u2f(out);
+            });
             {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
-                const uint32_t mn = ((xp & kAbs) == min1) ? m2f : m1f;
-                const float c2v = u2f(bfi(kAbs, mn, sgn ^ xp));
+                const uint32_t mn = (__builtin_fabsf(pvr) == min1) ? m2s : m1s;
+                const float c2v = u2f(__builtin_amdgcn_bitop3_b32(mn, f2u(pvr), kSign, 0x78));
                 const float tot = st.lp[r] + c2v;
                 st.pv[r] = __builtin_amdgcn_fmed3f(tot - c2v, -50.0f, 50.0f);
                 st.pt[r] = tot;
@@ -270,7 +321,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
                 float tot = st.li[r];
 #pragma unroll
                 for (int d = 0; d < DV; ++d) tot = tot + cv[d];
-                lds_sf(lane4 + 4u * (I::tot_word + 64 * r), tot);
+                lds_store_tid<4 * (I::tot_word + 64 * r)>(m0base, tot);
             }
         });
         wave_sync();

@@ -17,23 +17,23 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define RIA_HD __host__ __device__
+#define RIA_SORT_HD __host__ __device__
 #else
-#define RIA_HD
+#define RIA_SORT_HD
 #endif
 
 namespace ria {
 
 struct Suspect { int frame_bit; float abs_llr; };
-RIA_HD inline bool suspect_lt(const Suspect& a, const Suspect& b) { return a.abs_llr < b.abs_llr; }
+RIA_SORT_HD inline bool suspect_lt(const Suspect& a, const Suspect& b) { return a.abs_llr < b.abs_llr; }
 
 namespace sortx {
 
-template <class T> RIA_HD inline void swp(T& a, T& b) { T t = a; a = b; b = t; }
+template <class T> RIA_SORT_HD inline void swp(T& a, T& b) { T t = a; a = b; b = t; }
 
 // ---- bits/stl_heap.h
 template <class T, class C>
-RIA_HD inline void push_heap(T* first, int hole, int top, T value, C lt) {
+RIA_SORT_HD inline void push_heap(T* first, int hole, int top, T value, C lt) {
     int parent = (hole - 1) / 2;
     while (hole > top && lt(first[parent], value)) {
         first[hole] = first[parent];
@@ -43,7 +43,7 @@ RIA_HD inline void push_heap(T* first, int hole, int top, T value, C lt) {
     first[hole] = value;
 }
 template <class T, class C>
-RIA_HD inline void adjust_heap(T* first, int hole, int len, T value, C lt) {
+RIA_SORT_HD inline void adjust_heap(T* first, int hole, int len, T value, C lt) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -60,7 +60,7 @@ RIA_HD inline void adjust_heap(T* first, int hole, int len, T value, C lt) {
     push_heap(first, hole, top, value, lt);
 }
 template <class T, class C>
-RIA_HD inline void heap_sort(T* first, T* last, C lt) {   // __partial_sort(first, last, last)
+RIA_SORT_HD inline void heap_sort(T* first, T* last, C lt) {   // __partial_sort(first, last, last)
     const int len = static_cast<int>(last - first);
     if (len >= 2)
         for (int parent = (len - 2) / 2;; --parent) {
@@ -78,14 +78,14 @@ RIA_HD inline void heap_sort(T* first, T* last, C lt) {   // __partial_sort(firs
 
 // ---- bits/stl_algo.h
 template <class T, class C>
-RIA_HD inline void unguarded_linear_insert(T* last, C lt) {
+RIA_SORT_HD inline void unguarded_linear_insert(T* last, C lt) {
     T val = *last;
     T* next = last - 1;
     while (lt(val, *next)) { *last = *next; last = next; --next; }
     *last = val;
 }
 template <class T, class C>
-RIA_HD inline void insertion_sort(T* first, T* last, C lt) {
+RIA_SORT_HD inline void insertion_sort(T* first, T* last, C lt) {
     if (first == last) return;
     for (T* i = first + 1; i != last; ++i) {
         if (lt(*i, *first)) {
@@ -98,7 +98,7 @@ RIA_HD inline void insertion_sort(T* first, T* last, C lt) {
     }
 }
 template <class T, class C>
-RIA_HD inline T* partition_pivot(T* first, T* last, C lt) {   // __unguarded_partition_pivot
+RIA_SORT_HD inline T* partition_pivot(T* first, T* last, C lt) {   // __unguarded_partition_pivot
     T *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1;
     if (lt(*a, *b)) {
         if (lt(*b, *c)) swp(*first, *b); else if (lt(*a, *c)) swp(*first, *c); else swp(*first, *a);
@@ -122,7 +122,7 @@ RIA_HD inline T* partition_pivot(T* first, T* last, C lt) {   // __unguarded_par
 // range (the recursion of __introsort_loop): 3 * 64 ints are plenty (depth <= 2*log2 n).
 // depth_budget < 0: the library's 2*floor(log2 n); tests pass 0 to force the heapsort branch.
 template <class T, class C>
-RIA_HD inline void sort_exact_prefix(T* v, int n, int want, int* stack, C lt, int depth_budget = -1) {
+RIA_SORT_HD inline void sort_exact_prefix(T* v, int n, int want, int* stack, C lt, int depth_budget = -1) {
     if (n <= 0) return;
     const int limit = (want >= n) ? n : want + 16;   // positions at or beyond this never reach the prefix
     int lg = 0;
