@@ -27,13 +27,24 @@ __device__ __forceinline__ void wave_sync() {
 // data-independent chunks across the lanes; the Marsaglia polar rejection consumes draws in aligned
 // pairs, so acceptance is decided per pair in parallel and ranked with a ballot prefix count.
 __device__ inline void mt_seed_wave(uint32_t* st, uint32_t seed, int lane) {
-    if (lane == 0) {
-        uint32_t x = seed;
-        st[0] = x;
-        for (int i = 1; i < 624; ++i) {
-            x = 1812433253u * (x ^ (x >> 30)) + static_cast<uint32_t>(i);
-            st[i] = x;
+    // The seeding recurrence is serial, so it runs on the SCALAR unit: the value is wave-uniform (readfirstlane
+    // tells the compiler), the 4 ops per step are s_lshr/s_xor/s_mul/s_add and issue beside other waves'
+    // vector work; v_writelane parks word i in lane i%64 of a register, ten stores publish the state.
+    uint32_t x = __builtin_amdgcn_readfirstlane(seed);
+    uint32_t keep = x;   // word 0
+    (void)lane;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t reg = 0;
+        const int j0 = (r == 0) ? 1 : 0;
+        if (r == 0) reg = keep;   // all lanes hold word 0; lane 0 keeps it
+        const int jn = (r == 9) ? 624 - 576 : 64;
+        for (int j = j0; j < jn; ++j) {
+            x = 1812433253u * (x ^ (x >> 30)) + static_cast<uint32_t>(64 * r + j);
+            // lane select through M0: a second SGPR operand would exceed the constant-bus limit of one
+            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(x), "s"(j) : "m0");
         }
+        if (r < 9 || lane < 624 - 576) st[64 * r + lane] = reg;
     }
     wave_sync();
 }
