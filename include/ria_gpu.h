@@ -182,6 +182,29 @@ int ria_gpu_make_frames(ria_gpu_handle h, uint64_t seed, int first_seq, int n_fr
 int ria_gpu_channel_batch(ria_gpu_handle h, int kind, float snr_db, uint64_t seed, uint64_t first_frame,
                           float* samples_dev, int n_frames, void* stream);
 
+/* ---- acquisition: Zadoff-Chu preamble (sync::ZCSync, src/sync/zc_sync.hpp) -----------------------
+ * ria_gpu_sync_zc_batch replaces ZCSync::detect(samples, threshold, debug=false, root_mask, known_cfo_hz)
+ * (zc_sync.hpp:192-391) for n_buffers capture buffers of buf_len samples each (buffer b starts at
+ * samples_dev + b*stride).  root_mask bits 0..3 = PING/PONG/DATA/CONTROL roots 1/3/5/7 (ZC_ROOT_MASK_*).
+ * known_cfo_dev: per-buffer known CFO in Hz, or NULL for 0.  Results are bit-identical to the reference's
+ * ZCSyncResult for every field (snr_estimate included).  buf_len <= 16384. */
+typedef struct ria_zc_result {
+    int32_t detected;        /* ZCSyncResult::detected */
+    int32_t frame_type;      /* ZCFrameType: 0 PING 1 PONG 2 DATA 3 CONTROL 255 UNKNOWN */
+    int32_t start_sample;    /* first sample after the preamble, -1 if not detected */
+    int32_t root_detected;   /* best root even below threshold, -1 if none */
+    float correlation;
+    float cfo_hz;
+    float snr_estimate;
+    float reserved;
+} ria_zc_result;             /* 32 bytes */
+int ria_gpu_sync_zc_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                          float threshold, uint32_t root_mask, const float* known_cfo_dev,
+                          ria_zc_result* out_dev, void* stream);
+/* ZCSync::generatePreambleForRoot (zc_sync.hpp:133-190) into a HOST buffer (2512 samples); returns the
+ * sample count, or -needed if max_n is too small.  Bit-identical audio. */
+int ria_gpu_zc_preamble(ria_gpu_handle h, int root, float* out_host, int max_n);
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

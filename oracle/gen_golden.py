@@ -113,6 +113,21 @@ def main():
     for kind in range(5):
         rec[f"y_{kind}"] = R.channel(kind, 15.0, 77 + kind, x)
     np.savez_compressed(os.path.join(OUT, "channel_vectors.npz"), **rec)
+    # ---- ZC acquisition (sync::ZCSync): preambles and detect() results on noisy, CFO-shifted buffers
+    from check_against_ref import zc_test_buffer
+    rng = np.random.default_rng(4242)
+    rec = {f"preamble_{root}": R.zc_generate(root) for root in (1, 3, 5, 7)}
+    bufs, res, par = [], [], []
+    for t in range(40):
+        root = (1, 3, 5, 7)[t % 4]
+        snr_db = (-10, -5, 0, 5, 10)[t % 5]
+        cfo = (-20.0, -10.0, 0.0, 10.0, 20.0)[(t // 2) % 5]
+        off = int(rng.integers(0, 2000))
+        x = zc_test_buffer(rec[f"preamble_{root}"], 4512, off, snr_db, cfo, rng)
+        mask, known = ((15, 0.0), (12, 0.0), (15, cfo))[t % 3]
+        bufs.append(x); par.append((root, snr_db, cfo, off, mask, known)); res.append(R.zc_detect(x, 0.3, mask, known))
+    rec.update(buffers=np.stack(bufs), params=np.array(par, np.float32), results=np.stack(res))
+    np.savez_compressed(os.path.join(OUT, "zc_sync.npz"), **rec)
     print("done ->", OUT)
     return 0
 

@@ -60,8 +60,8 @@ class RxAux(C.Structure):
 
 def build_oracle():
     so = os.path.join(HERE, "libria_oracle.so")
-    src = os.path.join(HERE, "ria_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("ria_oracle.c", "ria_oracle_sync.c", "ria_oracle.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     return so
 
@@ -77,8 +77,22 @@ class Oracle:
         L.ro_ldpc_decode.argtypes = [C.POINTER(Ldpc), _f, C.c_int, C.c_int, C.c_float, _u8, _i]
         L.ro_decode_fixed_frame.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8, _u8, _i, _i]
         L.ro_crc16.restype = C.c_uint16
+        L.ro_zc_generate.argtypes = [C.c_int, _f, C.c_int]
+        L.ro_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
         self._geoms = {}
         self._codes = {}
+
+    def zc_generate(self, root):
+        out = np.zeros(4096, np.float32)
+        n = self.lib.ro_zc_generate(root, fp(out), len(out))
+        return out[:n].copy()
+
+    def zc_detect(self, samples, threshold=0.3, root_mask=15, known_cfo=0.0):
+        """-> float32[7] {detected, frame_type, start_sample, correlation, cfo_hz, snr_estimate, root}"""
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(7, np.float32)
+        self.lib.ro_zc_detect(fp(x), len(x), threshold, root_mask, known_cfo, fp(out))
+        return out
 
     def geom(self, mod, rate):
         key = (mod, rate)
@@ -191,7 +205,20 @@ class Ref:
         L.ref_ldpc_decode.argtypes = [C.c_int, _f, C.c_int, C.c_int, C.c_float, _u8, C.c_int, _i]
         L.ref_detect_data_sync.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _i, _f, _i]
         L.ref_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
+        L.ref_zc_generate.argtypes = [C.c_int, _f, C.c_int]
+        L.ref_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
         L.ref_quiet()
+
+    def zc_generate(self, root):
+        out = np.zeros(4096, np.float32)
+        n = self.lib.ref_zc_generate(root, fp(out), len(out))
+        return out[:n].copy()
+
+    def zc_detect(self, samples, threshold=0.3, root_mask=15, known_cfo=0.0):
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(7, np.float32)
+        self.lib.ref_zc_detect(fp(x), len(x), threshold, root_mask, known_cfo, fp(out))
+        return out
 
     def tx_frame(self, mod, rate, payload, seq):
         payload = np.ascontiguousarray(payload, np.uint8)

@@ -291,4 +291,28 @@ int ref_chirp_generate(float* out, int max_n) {
     return n;
 }
 
+// sync::ZCSync (src/sync/zc_sync.hpp:133-190 generatePreambleForRoot, :192-391 detect)
+int ref_zc_generate(int root, float* out, int max_n) {
+    ref_quiet();
+    sync::ZCSync z;
+    Samples s = z.generatePreambleForRoot(root);
+    int n = static_cast<int>(s.size());
+    if (n > max_n) return -n;
+    std::memcpy(out, s.data(), n * sizeof(float));
+    return n;
+}
+int ref_zc_detect(const float* samples, int n, float thr, int root_mask, float known_cfo, float* out7) {
+    ref_quiet();
+    sync::ZCSync z;
+    auto r = z.detect(SampleSpan(samples, n), thr, false, static_cast<uint8_t>(root_mask), known_cfo);
+    out7[0] = r.detected ? 1.f : 0.f;
+    out7[1] = static_cast<float>(static_cast<int>(r.frame_type));
+    out7[2] = static_cast<float>(r.start_sample);
+    out7[3] = r.correlation;
+    out7[4] = r.cfo_hz;
+    out7[5] = r.snr_estimate;
+    out7[6] = static_cast<float>(r.root_detected);
+    return r.detected ? 1 : 0;
+}
+
 }  // extern "C"

@@ -99,4 +99,11 @@ int ro_decode_fixed_frame(const float* llr, int n, int rate, int ch_deint, int b
 #ifdef __cplusplus
 }
 #endif
+/* ---- acquisition correlators (ria_oracle_sync.c) ---- */
+/* sync::ZCSync, src/sync/zc_sync.hpp: preamble synthesis and detection.
+ * out7 = {detected, frame_type, start_sample, correlation, cfo_hz, snr_estimate, root_detected} */
+int ro_zc_preamble_samples(void);
+int ro_zc_generate(int root, float* out, int max_n);
+int ro_zc_detect(const float* rx, int n, float threshold, int root_mask, float known_cfo_hz, float* out7);
+
 #endif

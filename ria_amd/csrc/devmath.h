@@ -98,14 +98,42 @@ RIA_HD float sincos_eval(double x, double x2, bool neg_table, int n) {
 
 RIA_HD uint32_t abstop12(float x) { return (f2u(x) >> 20) & 0x7ff; }
 
-// Valid for |y| < 120 (every angle on the RX path is within [-2pi, 2pi]); larger arguments take
-// glibc's reduce_large path, which this header does not restate (callers never reach it).
+// |y| >= 120: glibc's reduce_large (sincosf.h): 3 x 32-bit words of 4/pi picked by the exponent, a 96-bit
+// product, n = the two top bits; the sync correlators mix at 2*pi*f*t with t up to seconds, so they get here.
+RIA_HD double sincos_reduce_large(uint32_t xi, int* np) {
+    const uint32_t inv_pio4[24] = {0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
+                                   0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu,
+                                   0xf534ddc0u, 0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u,
+                                   0x993c4390u, 0x3c439041u};
+    const uint32_t* arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (xi >> 23) & 7;
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = static_cast<uint64_t>(static_cast<uint32_t>(xi * arr[0]));
+    const uint64_t res1 = static_cast<uint64_t>(xi) * arr[4];
+    const uint64_t res2 = static_cast<uint64_t>(xi) * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = static_cast<int>(n);
+    return static_cast<double>(static_cast<int64_t>(res0)) * 0x1.921FB54442D18p-62;
+}
+
 RIA_HD float sinf_glibc(float y) {
     double x = y;
     if (abstop12(y) < 0x3f4) {  // |y| < pi/4 : abstop12(0x1.921FB6p-1f) = 0x3f4
         double s = x * x;
         if (abstop12(y) < 0x398) return y;  // |y| < 2^-12 : abstop12(0x1p-12f) = 0x398
         return sincos_eval(x, s, false, 0);
+    }
+    if (abstop12(y) >= 0x42f) {  // |y| >= 120 (finite)
+        const uint32_t xi = f2u(y);
+        int n;
+        x = sincos_reduce_large(xi, &n);
+        n += static_cast<int>(xi >> 31);
+        const double sgl = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return sincos_eval(x * sgl, x * x, (n & 2) != 0, n - static_cast<int>(xi >> 31));
     }
     const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p0;
     double r = x * hpi_inv;
@@ -120,6 +148,14 @@ RIA_HD float cosf_glibc(float y) {
         double x2 = x * x;
         if (abstop12(y) < 0x398) return 1.0f;
         return sincos_eval(x, x2, false, 1);
+    }
+    if (abstop12(y) >= 0x42f) {  // |y| >= 120 (finite)
+        const uint32_t xi = f2u(y);
+        int n;
+        x = sincos_reduce_large(xi, &n);
+        const int ns = n + static_cast<int>(xi >> 31);
+        const double sgl = ((ns & 3) == 1 || (ns & 3) == 2) ? -1.0 : 1.0;
+        return sincos_eval(x * sgl, x * x, (ns & 2) != 0, n ^ 1);
     }
     const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p0;
     double r = x * hpi_inv;
@@ -162,6 +198,19 @@ RIA_HD float logf_glibc(float x) {
     y = dfma(A0, r2, y);
     y = dfma(y, r2, y0 + r);
     return (float)y;
+}
+
+// ---------------------------------------------------------------- log10f (positive normal x)
+// glibc 2.35 sysdeps/ieee754/flt-32/e_log10f.c (fdlibm form on top of logf)
+RIA_HD float log10f_glibc(float x) {
+    const float ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;
+    int32_t hx = (int32_t)f2u(x);
+    int32_t k = (hx >> 23) - 127;
+    int32_t i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+    hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+    float y = (float)(k + i);
+    float z = y * log10_2lo + ivln10 * logf_glibc(u2f((uint32_t)hx));
+    return z + y * log10_2hi;
 }
 
 // ---------------------------------------------------------------- atanf / atan2f (fdlibm float)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/ria_gpu.h"
+#include "devmath.h"
 
 namespace ria {
 
@@ -520,6 +521,45 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
             }
         }
     return t;
+}
+
+// ---------------------------------------------------------------- Zadoff-Chu preamble (sync::ZCSync)
+// zc_sync.hpp:420-436 (generateZC, N = 127 odd), :147-157 (8x linear interpolation), :133-190 (preamble).
+// The float functions are devmath.h's host build (bit-identical to glibc, tests/test_devmath_host.py).
+constexpr int kZcChips = 127, kZcUpsample = 8, kZcRepSamples = kZcChips * kZcUpsample, kZcGapSamples = 480;
+inline void build_zc_reference(int root, std::vector<float>& re, std::vector<float>& im) {   // [1016] interpolated reference
+    float zr[kZcChips], zi[kZcChips];
+    for (int n = 0; n < kZcChips; ++n) {
+        float phase = static_cast<float>(-3.14159265358979323846 * root * n * (n + 1) / kZcChips);
+        zr[n] = cosf_glibc(phase);
+        zi[n] = sinf_glibc(phase);
+    }
+    re.resize(kZcRepSamples); im.resize(kZcRepSamples);
+    for (int i = 0; i < kZcRepSamples; ++i) {
+        float chip_pos = static_cast<float>(i) / kZcUpsample;
+        int c = static_cast<int>(chip_pos);
+        float frac = chip_pos - c;
+        if (c < kZcChips - 1) {
+            float a = 1.0f - frac;
+            re[i] = zr[c] * a + zr[c + 1] * frac;
+            im[i] = zi[c] * a + zi[c + 1] * frac;
+        } else { re[i] = zr[c]; im[i] = zi[c]; }
+    }
+}
+inline std::vector<float> build_zc_preamble(int root) {
+    std::vector<float> re, im, out(2 * kZcRepSamples + kZcGapSamples, 0.0f);
+    build_zc_reference(root, re, im);
+    for (int rep = 0; rep < 2; ++rep)
+        for (int i = 0; i < kZcRepSamples; ++i) {
+            int g = rep * kZcRepSamples + i;
+            float t = static_cast<float>(g) / 48000.0f;
+            float ph = static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(1500.0f) * static_cast<double>(t));
+            out[g] = re[i] * cosf_glibc(ph) - im[i] * sinf_glibc(ph);
+        }
+    float max_amp = 0.0f;
+    for (int i = 0; i < 2 * kZcRepSamples; ++i) max_amp = std::max(max_amp, std::fabs(out[i]));
+    if (max_amp > 0.0f) { float scale = 0.8f / max_amp; for (int i = 0; i < 2 * kZcRepSamples; ++i) out[i] *= scale; }
+    return out;
 }
 
 // ---------------------------------------------------------------- RX gather (both de-interleavers folded)

@@ -24,6 +24,7 @@
 #include "recovery_kernels.hip.h"
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
+#include "sync_kernels.hip.h"
 
 using namespace ria;
 
@@ -38,6 +39,7 @@ struct ria_gpu {
     void* d_row_deg = nullptr; void* d_row_var = nullptr; void* d_col_deg = nullptr; void* d_col_slot = nullptr;
     void* d_gather = nullptr; void* d_gather_nochan = nullptr;
     void* d_crc_bit = nullptr; void* d_crc_init = nullptr;
+    void* d_zc_ref = nullptr;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
     void* d_demod_const = nullptr;
     void* d_tx_const = nullptr;
@@ -345,7 +347,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
-                    h->d_crc_bit, h->d_crc_init, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
+                    h->d_crc_bit, h->d_crc_init, h->d_zc_ref, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
                     h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -417,6 +419,14 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
         CREATE_TRY(upload(&h->d_crc_init, init));
     }
     h->crc.build(4 * 68);
+    {
+        std::vector<float> zc(static_cast<size_t>(4) * kZcRepSamples * 2), re, im;
+        for (int r = 0; r < 4; ++r) {
+            build_zc_reference(2 * r + 1, re, im);
+            for (int i = 0; i < kZcRepSamples; ++i) { zc[(static_cast<size_t>(r) * kZcRepSamples + i) * 2] = re[i]; zc[(static_cast<size_t>(r) * kZcRepSamples + i) * 2 + 1] = im[i]; }
+        }
+        CREATE_TRY(upload(&h->d_zc_ref, zc));
+    }
     CREATE_TRY(upload(&h->d_twiddle, build_twiddles()));
     CREATE_TRY(upload(&h->d_nco, build_nco_table(g.frame_samples)));
     {
@@ -718,6 +728,35 @@ __global__ void debug_math_kernel(int op, const float* a, const float* b, int n,
         default: r = fsqrt(x); break;
     }
     out[i] = r;
+}
+
+int ria_gpu_sync_zc_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                          float threshold, uint32_t root_mask, const float* known_cfo_dev, ria_zc_result* out_dev,
+                          void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_buffers == 0) return RIA_OK;
+    if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || buf_len > 16384 || stride < buf_len)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_zc_batch: bad arguments");
+    ZcArgs A{};
+    A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.n_buffers = n_buffers; A.threshold = threshold;
+    A.root_mask = root_mask & 15u; A.known_cfo = known_cfo_dev; A.ref = static_cast<const float2*>(h->d_zc_ref); A.out = out_dev;
+    const int lds = buf_len * static_cast<int>(sizeof(float2)) + 4 * static_cast<int>(sizeof(ZcRootOut));
+    static std::atomic<int> lds_opted{0};
+    if (lds > lds_opted.load()) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(zc_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        lds_opted.store(lds);
+    }
+    hipLaunchKernelGGL(zc_detect_kernel, dim3(n_buffers), dim3(256), lds, static_cast<hipStream_t>(stream), A);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_zc_preamble(ria_gpu_handle h, int root, float* out_host, int max_n) {
+    if (!h || !out_host) return RIA_ERR_INVALID;
+    std::vector<float> p = build_zc_preamble(root);
+    if (static_cast<int>(p.size()) > max_n) return -static_cast<int>(p.size());
+    std::memcpy(out_host, p.data(), p.size() * sizeof(float));
+    return static_cast<int>(p.size());
 }
 
 int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n, float* out_dev,

@@ -152,6 +152,27 @@ class RxEngine:
                                                    _ptr(samples), n, _stream_ptr()))
         return samples
 
+    ZC_RESULT = np.dtype([("detected", "<i4"), ("frame_type", "<i4"), ("start_sample", "<i4"), ("root_detected", "<i4"),
+                          ("correlation", "<f4"), ("cfo_hz", "<f4"), ("snr_estimate", "<f4"), ("reserved", "<f4")])
+
+    def sync_zc(self, buffers, threshold=0.3, root_mask=15, known_cfo=None):
+        """ZCSync::detect over a batch: buffers float32 [n, buf_len] on the device -> structured array."""
+        n, buf_len = buffers.shape
+        assert buffers.dtype == torch.float32 and buffers.is_contiguous()
+        out = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        if known_cfo is not None:
+            assert known_cfo.dtype == torch.float32 and known_cfo.numel() == n
+        self._check(self.lib.ria_gpu_sync_zc_batch(self.h, _ptr(buffers), buf_len, buf_len, n, float(threshold),
+                                                   int(root_mask), _ptr(known_cfo), _ptr(out), _stream_ptr()))
+        return self._status_array(out, self.ZC_RESULT)
+
+    def zc_preamble(self, root):
+        out = np.zeros(4096, np.float32)
+        n = self.lib.ria_gpu_zc_preamble(self.h, int(root), out.ctypes.data, len(out))
+        if n < 0:
+            raise capi.RiaError("zc_preamble: buffer too small")
+        return out[:n].copy()
+
     def debug_math(self, op, a, b=None):
         out = torch.empty_like(a)
         self._check(self.lib.ria_gpu_debug_math(self.h, op, _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream_ptr()))

@@ -8,7 +8,7 @@ using namespace ria;
 int main(int argc, char** argv) {
     uint32_t stride = argc > 1 ? static_cast<uint32_t>(atoi(argv[1])) : 97;
     long bad = 0, n = 0;
-    uint32_t lim = f2u(120.0f);
+    uint32_t lim = 0x7f800000u;   // every finite float: the |x| >= 120 branch (reduce_large) serves the sync mixers
     for (uint64_t u = 0; u < lim; u += stride)
         for (int sg = 0; sg < 2; ++sg) {
             float x = u2f(static_cast<uint32_t>(u) | (sg ? 0x80000000u : 0u));
@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     for (uint64_t u = 1; u < 0x7f800000u; u += stride) {
         float x = u2f(static_cast<uint32_t>(u));
         bad += f2u(logf_glibc(x)) != f2u(logf(x));
+        if (u >= 0x00800000u) { bad += f2u(log10f_glibc(x)) != f2u(log10f(x)); ++n; }
         ++n;
     }
     std::mt19937_64 rng(99);

@@ -241,6 +241,51 @@ def test_make_frames_are_valid_v2_frames(oracle):
     assert len({bytes(x) for x in info[:, 17:158]}) == 16
 
 
+def _zc_fields(r):
+    return np.stack([r["detected"].astype(np.float32), r["frame_type"].astype(np.float32), r["start_sample"].astype(np.float32),
+                     r["correlation"], r["cfo_hz"], r["snr_estimate"], r["root_detected"].astype(np.float32)], axis=1)
+
+
+def test_zc_sync_matches_reference_golden(golden):
+    """ria_gpu_sync_zc_batch vs ZCSyncResult recorded from the reference (every field bit-exact),
+    and the host-synthesised preamble audio."""
+    e = engine("QAM16", "R1_2")
+    g = golden("zc_sync")
+    for root in (1, 3, 5, 7):
+        assert np.array_equal(e.zc_preamble(root).view(np.uint32), g[f"preamble_{root}"].view(np.uint32))
+    import torch
+    bufs, par, ref = g["buffers"], g["params"], g["results"]
+    for mask, known in {(int(p[4]), 0.0 if p[5] == 0 else None) for p in par}:
+        sel = [i for i, p in enumerate(par) if int(p[4]) == mask and ((p[5] == 0) == (known == 0.0))]
+        kc = None if known == 0.0 else dev(par[sel, 5].astype(np.float32))
+        out = _zc_fields(e.sync_zc(dev(bufs[sel]), 0.3, mask, kc))
+        assert np.array_equal(out.view(np.uint32), ref[sel].view(np.uint32)), (mask, known, out, ref[sel])
+
+
+def test_zc_sync_matches_oracle_random_buffers(oracle):
+    """More buffers than the fixture holds: lengths, offsets, SNRs, CFOs, truncated preambles; GPU vs oracle."""
+    sys_path_oracle = __import__("check_against_ref")
+    e = engine("QAM16", "R1_2")
+    rng = np.random.default_rng(31337)
+    pre = {root: oracle.zc_generate(root) for root in (1, 3, 5, 7)}
+    for buf_len in (4512, 3000, 1016, 1500, 900, 8000):
+        bufs, known = [], []
+        for t in range(48):
+            root = (1, 3, 5, 7)[t % 4]
+            snr_db = (-10, -5, 0, 5, 10, 25)[t % 6]
+            cfo = (-23.0, -10.0, 0.0, 10.0, 23.0)[t % 5]
+            off = int(rng.integers(0, max(1, buf_len - 1200)))
+            bufs.append(sys_path_oracle.zc_test_buffer(pre[root], buf_len, off, snr_db, cfo, rng))
+            known.append(cfo if t % 3 == 2 else 0.0)
+        bufs = np.stack(bufs)
+        known = np.array(known, np.float32)
+        for mask in (15, 12, 5):
+            out = _zc_fields(e.sync_zc(dev(bufs), 0.3, mask, dev(known)))
+            for i in range(len(bufs)):
+                exp = oracle.zc_detect(bufs[i], 0.3, mask, float(known[i]))
+                assert np.array_equal(out[i].view(np.uint32), exp.view(np.uint32)), (buf_len, mask, i, out[i], exp)
+
+
 def test_loopback_round_trip_full_size():
     """Size-independent property at bench scale: make_frames -> tx -> AWGN 20 dB -> rx returns the
     transmitted bytes for (nearly) every frame, and frame_valid agrees with byte equality."""

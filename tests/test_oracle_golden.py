@@ -112,3 +112,13 @@ def test_frame_geometry_named_shape(oracle):
         (12, 47, 188, 14, 18432, 2632)
     g = oracle.geom(po.DQPSK, po.R1_2)
     assert (g.n_pilot, g.n_data, g.bits_per_symbol, g.frame_samples, g.n_llr) == (6, 53, 106, 31104, 2650)
+
+
+def test_zc_sync_oracle_matches_reference_golden(oracle, golden):
+    """sync::ZCSync (zc_sync.hpp): preamble audio and every ZCSyncResult field, bit for bit."""
+    g = golden("zc_sync")
+    for root in (1, 3, 5, 7):
+        assert np.array_equal(oracle.zc_generate(root).view(np.uint32), g[f"preamble_{root}"].view(np.uint32))
+    for x, p, r in zip(g["buffers"], g["params"], g["results"]):
+        out = oracle.zc_detect(x, 0.3, int(p[4]), float(p[5]))
+        assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (p, out, r)
