@@ -205,6 +205,26 @@ int ria_gpu_sync_zc_batch(ria_gpu_handle h, const float* samples_dev, int64_t st
  * sample count, or -needed if max_n is too small.  Bit-identical audio. */
 int ria_gpu_zc_preamble(ria_gpu_handle h, int root, float* out_host, int max_n);
 
+/* ---- acquisition: dual chirp (sync::ChirpSync, src/sync/chirp_sync.hpp) ----------------------------
+ * ria_gpu_sync_chirp_batch replaces ChirpSync::detectDualChirp(samples, threshold) (chirp_sync.hpp:352-512)
+ * with the OFDM-CHIRP configuration (300 -> 2700 Hz, 500 ms, 100 ms gap, dual chirp; getChirpConfig,
+ * ofdm_chirp_waveform.cpp:46-56) for n_buffers buffers of buf_len samples (buffer b at samples_dev + b*stride).
+ * Every field is bit-identical to the reference's DualChirpResult. */
+typedef struct ria_chirp_result {
+    int32_t success;
+    int32_t up_chirp_start;      /* CFO-corrected, -1 if not detected */
+    int32_t down_chirp_start;
+    float cfo_hz;
+    float up_correlation;
+    float down_correlation;
+    int32_t reserved[2];
+} ria_chirp_result;              /* 32 bytes */
+int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                             float threshold, ria_chirp_result* out_dev, void* stream);
+/* ChirpSync::generate (chirp_sync.hpp:61-108): the 57 600-sample dual-chirp preamble into a HOST buffer;
+ * returns the sample count or -needed. */
+int ria_gpu_chirp_preamble(ria_gpu_handle h, float* out_host, int max_n);
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

@@ -35,6 +35,33 @@ FRAME_SETS = [
 ]
 
 
+CHIRP_CASES = [(120000, 20000, 5, 0.0), (120000, 1000, 0, 25.0), (120000, 61000, -5, -50.0), (120000, 40000, -10, 50.0),
+               (120000, 30000, 10, -25.0), (120000, 62400, 0, 0.0), (70000, 5000, 5, 10.0), (60000, 1200, 0, 0.0),
+               (57600, 0, 15, 0.0), (100000, 50000, 5, 0.0), (136072, 60000, 0, 30.0), (52000, 0, 10, 0.0),
+               (120000, 15000, -15, 0.0), (120000, 33333, 3, 75.0), (120000, 44444, 3, -75.0), (120000, 10000, 20, 120.0)]
+
+
+def chirp_buffer(chirp, case, idx):
+    import zlib
+    from check_against_ref import zc_test_buffer
+    buf_len, off, snr_db, cfo = case
+    x = zc_test_buffer(chirp, buf_len, off, snr_db, cfo, np.random.default_rng(9000 + idx))
+    return x, zlib.crc32(x.tobytes())
+
+
+def chirp_fixture(R):
+    chirp = R.chirp_generate()
+    rec = {"preamble_crc": np.array([__import__("zlib").crc32(chirp.tobytes())], np.uint32), "cases": np.array(CHIRP_CASES, np.float32)}
+    crcs, res = [], []
+    for i, case in enumerate(CHIRP_CASES):
+        x, crc = chirp_buffer(chirp, case, i)
+        crcs.append(crc)
+        res.append(R.chirp_detect(x, 0.15))
+    rec["buffer_crc"] = np.array(crcs, np.uint32)
+    rec["results"] = np.stack(res)
+    return rec
+
+
 def main():
     if not po.Ref.available():
         print("needs oracle/_ref/libria_ref.so (make -C oracle ref)")
@@ -128,6 +155,11 @@ def main():
         bufs.append(x); par.append((root, snr_db, cfo, off, mask, known)); res.append(R.zc_detect(x, 0.3, mask, known))
     rec.update(buffers=np.stack(bufs), params=np.array(par, np.float32), results=np.stack(res))
     np.savez_compressed(os.path.join(OUT, "zc_sync.npz"), **rec)
+    # ---- dual-chirp acquisition: the buffers (480 KB each) are regenerated by the tests from the recipe
+    # (seeded numpy noise + the preamble); the fixture holds the recipe, a checksum per buffer and the
+    # reference's DualChirpResult
+    rec = chirp_fixture(R)
+    np.savez_compressed(os.path.join(OUT, "chirp_sync.npz"), **rec)
     print("done ->", OUT)
     return 0
 

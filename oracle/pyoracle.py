@@ -79,6 +79,8 @@ class Oracle:
         L.ro_crc16.restype = C.c_uint16
         L.ro_zc_generate.argtypes = [C.c_int, _f, C.c_int]
         L.ro_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
+        L.ro_chirp_generate.argtypes = [_f, C.c_int]
+        L.ro_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
         self._geoms = {}
         self._codes = {}
 
@@ -92,6 +94,18 @@ class Oracle:
         x = np.ascontiguousarray(samples, np.float32)
         out = np.zeros(7, np.float32)
         self.lib.ro_zc_detect(fp(x), len(x), threshold, root_mask, known_cfo, fp(out))
+        return out
+
+    def chirp_generate(self):
+        out = np.zeros(60000, np.float32)
+        n = self.lib.ro_chirp_generate(fp(out), len(out))
+        return out[:n].copy()
+
+    def chirp_detect(self, samples, threshold=0.15):
+        """-> float32[6] {success, up_start, down_start, cfo_hz, up_corr, down_corr}"""
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(6, np.float32)
+        self.lib.ro_chirp_detect(fp(x), len(x), threshold, fp(out))
         return out
 
     def geom(self, mod, rate):
@@ -205,6 +219,7 @@ class Ref:
         L.ref_ldpc_decode.argtypes = [C.c_int, _f, C.c_int, C.c_int, C.c_float, _u8, C.c_int, _i]
         L.ref_detect_data_sync.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _i, _f, _i]
         L.ref_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
+        L.ref_chirp_generate.argtypes = [_f, C.c_int]
         L.ref_zc_generate.argtypes = [C.c_int, _f, C.c_int]
         L.ref_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
         L.ref_quiet()
@@ -213,6 +228,17 @@ class Ref:
         out = np.zeros(4096, np.float32)
         n = self.lib.ref_zc_generate(root, fp(out), len(out))
         return out[:n].copy()
+
+    def chirp_generate(self):
+        out = np.zeros(60000, np.float32)
+        n = self.lib.ref_chirp_generate(fp(out), len(out))
+        return out[:n].copy()
+
+    def chirp_detect(self, samples, threshold=0.15):
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(6, np.float32)
+        self.lib.ref_chirp_detect(fp(x), len(x), threshold, fp(out))
+        return out
 
     def zc_detect(self, samples, threshold=0.3, root_mask=15, known_cfo=0.0):
         x = np.ascontiguousarray(samples, np.float32)

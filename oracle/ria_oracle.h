@@ -105,5 +105,9 @@ int ro_decode_fixed_frame(const float* llr, int n, int rate, int ch_deint, int b
 int ro_zc_preamble_samples(void);
 int ro_zc_generate(int root, float* out, int max_n);
 int ro_zc_detect(const float* rx, int n, float threshold, int root_mask, float known_cfo_hz, float* out7);
+/* sync::ChirpSync, src/sync/chirp_sync.hpp: dual-chirp synthesis (57 600 samples) and detectDualChirp.
+ * out6 = {success, up_chirp_start, down_chirp_start, cfo_hz, up_correlation, down_correlation} */
+int ro_chirp_generate(float* out, int max_n);
+int ro_chirp_detect(const float* s, int n, float threshold, float* out6);
 
 #endif

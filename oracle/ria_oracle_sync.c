@@ -205,3 +205,229 @@ int ro_zc_detect(const float* rx, int n, float threshold, int root_mask, float k
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------ chirp
+ * sync::ChirpSync   src/sync/chirp_sync.hpp   generateTemplate :874-900, generate :61-108, initFFT :573-623,
+ *                   detectChirpTemplateFFT :627-712, detectChirpTemplate :717-818,
+ *                   computeComplexTemplateCorrelation :829-851, detectDualChirp :352-512
+ * FFT: src/dsp/fft.cpp:83-128 (radix-2 DIT, twiddles cosf/sinf(-2*pi*k/N), inverse = conjugated twiddles + 1/N).
+ */
+#define CH_LEN 24000      /* 500 ms */
+#define CH_GAP 4800       /* 100 ms */
+#define CH_FFT 131072
+typedef struct { float re, im; } scf;
+
+static float* g_ch_up_sin, *g_ch_up_cos, *g_ch_dn_sin, *g_ch_dn_cos;
+static float g_ch_up_energy, g_ch_dn_energy;
+static scf* g_ch_tw;          /* [CH_FFT/2] */
+static scf* g_ch_up_fft, *g_ch_dn_fft;   /* conj(FFT(template)) */
+
+static float ch_up_phase(float t) {
+    float T = 500.0f / 1000.0f, k = (2700.0f - 300.0f) / T;
+    return (float)(2.0f * M_PI * (300.0f * t + 0.5f * k * t * t));
+}
+static float ch_dn_phase(float t) {
+    float T = 500.0f / 1000.0f, k = (2700.0f - 300.0f) / T;
+    return (float)(2.0f * M_PI * (2700.0f * t - 0.5f * k * t * t));
+}
+static void ch_fft(scf* data, int inverse) {
+    int size = CH_FFT, j = 0;
+    for (int i = 0; i < size - 1; ++i) {
+        if (i < j) { scf t = data[i]; data[i] = data[j]; data[j] = t; }
+        int k = size / 2;
+        while (k <= j) { j -= k; k /= 2; }
+        j += k;
+    }
+    for (int len = 2; len <= size; len *= 2) {
+        int half = len / 2, step = size / len;
+        for (int i = 0; i < size; i += len)
+            for (int k = 0; k < half; ++k) {
+                scf w = g_ch_tw[k * step];
+                if (inverse) w.im = -w.im;
+                scf d = data[i + k + half], a = data[i + k], t;
+                t.re = w.re * d.re - w.im * d.im;
+                t.im = w.re * d.im + w.im * d.re;
+                data[i + k + half].re = a.re - t.re; data[i + k + half].im = a.im - t.im;
+                data[i + k].re = a.re + t.re; data[i + k].im = a.im + t.im;
+            }
+    }
+    if (inverse) {
+        float scale = 1.0f / (float)size;
+        for (int i = 0; i < size; ++i) { data[i].re *= scale; data[i].im *= scale; }
+    }
+}
+static void ch_init(void) {
+    if (g_ch_tw) return;
+    g_ch_up_sin = (float*)malloc(sizeof(float) * CH_LEN); g_ch_up_cos = (float*)malloc(sizeof(float) * CH_LEN);
+    g_ch_dn_sin = (float*)malloc(sizeof(float) * CH_LEN); g_ch_dn_cos = (float*)malloc(sizeof(float) * CH_LEN);
+    g_ch_up_energy = 0.0f; g_ch_dn_energy = 0.0f;
+    for (int i = 0; i < CH_LEN; ++i) {
+        float t = (float)i / 48000.0f;
+        float p = ch_up_phase(t);
+        g_ch_up_sin[i] = sinf(p); g_ch_up_cos[i] = cosf(p);
+        g_ch_up_energy += g_ch_up_sin[i] * g_ch_up_sin[i];
+    }
+    for (int i = 0; i < CH_LEN; ++i) {
+        float t = (float)i / 48000.0f;
+        float p = ch_dn_phase(t);
+        g_ch_dn_sin[i] = sinf(p); g_ch_dn_cos[i] = cosf(p);
+        g_ch_dn_energy += g_ch_dn_sin[i] * g_ch_dn_sin[i];
+    }
+    scf* tw = (scf*)malloc(sizeof(scf) * CH_FFT / 2);
+    for (int k = 0; k < CH_FFT / 2; ++k) {
+        float angle = (float)(-2.0f * M_PI * (double)k / (double)CH_FFT);
+        tw[k].re = cosf(angle); tw[k].im = sinf(angle);
+    }
+    g_ch_tw = tw;
+    g_ch_up_fft = (scf*)calloc(CH_FFT, sizeof(scf));
+    g_ch_dn_fft = (scf*)calloc(CH_FFT, sizeof(scf));
+    for (int i = 0; i < CH_LEN; ++i) {
+        g_ch_up_fft[i].re = g_ch_up_cos[i]; g_ch_up_fft[i].im = g_ch_up_sin[i];
+        g_ch_dn_fft[i].re = g_ch_dn_cos[i]; g_ch_dn_fft[i].im = g_ch_dn_sin[i];
+    }
+    ch_fft(g_ch_up_fft, 0); ch_fft(g_ch_dn_fft, 0);
+    for (int i = 0; i < CH_FFT; ++i) { g_ch_up_fft[i].im = -g_ch_up_fft[i].im; g_ch_dn_fft[i].im = -g_ch_dn_fft[i].im; }
+}
+
+int ro_chirp_generate(float* out, int max_n) { /* :61-108, dual chirp, tx_cfo 0 */
+    const int total = 2 * CH_LEN + 2 * CH_GAP;
+    if (max_n < total) return -total;
+    memset(out, 0, sizeof(float) * (size_t)total);
+    float T = 500.0f / 1000.0f, k = (2700.0f - 300.0f) / T, cfo = 0.0f;
+    float f_start_up = 300.0f + cfo, f_start_down = 2700.0f + cfo;
+    for (int i = 0; i < CH_LEN; ++i) {
+        float t = (float)i / 48000.0f;
+        float phase = (float)(2.0f * M_PI * (f_start_up * t + 0.5f * k * t * t));
+        out[i] = 0.5f * sinf(phase);
+    }
+    for (int i = 0; i < CH_LEN; ++i) {
+        float t = (float)i / 48000.0f;
+        float phase = (float)(2.0f * M_PI * (f_start_down * t - 0.5f * k * t * t));
+        out[CH_LEN + CH_GAP + i] = 0.5f * sinf(phase);
+    }
+    return total;
+}
+
+static float ch_td_corr(const float* s, int n, int offset, const float* tsin, const float* tcos, float tmpl_energy) { /* :829-851 */
+    if (offset + CH_LEN > n) return 0.0f;
+    float ci = 0.0f, cq = 0.0f, e = 0.0f;
+    for (int i = 0; i < CH_LEN; ++i) {
+        float x = s[offset + i];
+        ci += x * tcos[i];
+        cq += x * tsin[i];
+        e += x * x;
+    }
+    float denom = sqrtf(e * tmpl_energy);
+    if (denom < 1e-10f) return 0.0f;
+    return sqrtf(ci * ci + cq * cq) / denom;
+}
+
+/* detectChirpTemplate: returns position (or -1) and the correlation */
+static int ch_detect_template(const float* s, int n, int down, float threshold, float* corr_out) {
+    const float* tsin = down ? g_ch_dn_sin : g_ch_up_sin;
+    const float* tcos = down ? g_ch_dn_cos : g_ch_up_cos;
+    const float tmpl_energy = down ? g_ch_dn_energy : g_ch_up_energy;
+    *corr_out = 0.0f;
+    if (n < CH_LEN) return -1;
+    if (n >= 2 * CH_LEN) { /* detectChirpTemplateFFT :627-712 */
+        const scf* tf = down ? g_ch_dn_fft : g_ch_up_fft;
+        const int fft_in = n < CH_FFT ? n : CH_FFT;
+        const int search_len = fft_in - CH_LEN;
+        scf* buf = (scf*)calloc(CH_FFT, sizeof(scf));
+        for (int i = 0; i < fft_in; ++i) buf[i].re = s[i];
+        ch_fft(buf, 0);
+        for (int i = 0; i < CH_FFT; ++i) { /* signal_fft * tmpl_fft (std::complex operator*) */
+            scf a = buf[i], b = tf[i];
+            buf[i].re = a.re * b.re - a.im * b.im;
+            buf[i].im = a.re * b.im + a.im * b.re;
+        }
+        ch_fft(buf, 1);
+        float* cum = (float*)malloc(sizeof(float) * (size_t)(fft_in + 1));
+        cum[0] = 0.0f;
+        for (int i = 0; i < fft_in; ++i) cum[i + 1] = cum[i] + s[i] * s[i];
+        float best = 0.0f;
+        int best_pos = -1;
+        for (int pos = 0; pos < search_len; ++pos) {
+            float mag = hypotf(buf[pos].re, buf[pos].im);
+            float se = cum[pos + CH_LEN] - cum[pos];
+            float denom = sqrtf(se * tmpl_energy);
+            float nc = (denom > 1e-10f) ? mag / denom : 0.0f;
+            if (nc > best) { best = nc; best_pos = pos; }
+        }
+        free(buf); free(cum);
+        *corr_out = best;
+        return (best < threshold) ? -1 : best_pos;
+    }
+    /* time-domain fallback :759-817 */
+    const int search_len = n - CH_LEN;
+    float best = 0.0f;
+    int best_pos = -1;
+    for (int pos = 0; pos < search_len; pos += 48) {
+        float c = ch_td_corr(s, n, pos, tsin, tcos, tmpl_energy);
+        if (c > best) { best = c; best_pos = pos; }
+    }
+    *corr_out = best;
+    if (best_pos < 0 || best < threshold * 0.3f) return -1;
+    int fine_start = best_pos - 48 < 0 ? 0 : best_pos - 48;
+    int fine_end = best_pos + 48 > search_len ? search_len : best_pos + 48;
+    for (int pos = fine_start; pos <= fine_end; ++pos) {
+        float c = ch_td_corr(s, n, pos, tsin, tcos, tmpl_energy);
+        if (c > best) { best = c; best_pos = pos; }
+    }
+    if (best_pos > 0 && best_pos < search_len - 1) {
+        float c0 = ch_td_corr(s, n, best_pos - 1, tsin, tcos, tmpl_energy);
+        float c1 = best;
+        float c2 = ch_td_corr(s, n, best_pos + 1, tsin, tcos, tmpl_energy);
+        float denom = 2.0f * (c0 - 2.0f * c1 + c2);
+        if (fabsf(denom) > 1e-10f) {
+            float delta = (c0 - c2) / denom;
+            float lo = (1.0f < delta) ? 1.0f : delta;   /* std::min(1.0f, delta) */
+            delta = (-1.0f < lo) ? lo : -1.0f;          /* std::max(-1.0f, .) */
+            best_pos = (int)roundf((float)best_pos + delta);
+        }
+    }
+    *corr_out = best;
+    return (best >= threshold) ? best_pos : -1;
+}
+
+/* out6 = {success, up_chirp_start, down_chirp_start, cfo_hz, up_correlation, down_correlation} */
+int ro_chirp_detect(const float* s, int n, float threshold, float* out6) { /* detectDualChirp :352-512 */
+    ch_init();
+    out6[0] = 0.f; out6[1] = -1.f; out6[2] = -1.f; out6[3] = 0.f; out6[4] = 0.f; out6[5] = 0.f;
+    if (n < 2 * CH_LEN + CH_GAP) return 0;
+    float up_corr, down_corr;
+    int up_pos = ch_detect_template(s, n, 0, threshold, &up_corr);
+    out6[4] = up_corr;
+    if (up_pos < 0) return 0;
+    long long down_search_start = (long long)up_pos + CH_LEN / 2;
+    long long expected_down_pos = (long long)up_pos + CH_LEN + CH_GAP;
+    long long min_search_len = 2 * CH_LEN + 1000;
+    long long a = expected_down_pos + 10000 + CH_LEN, b = down_search_start + min_search_len;
+    long long down_search_end = (a > b) ? a : b;
+    if (down_search_end > n) down_search_end = n;
+    if (down_search_start >= n) return 0;
+    if (down_search_end <= down_search_start + CH_LEN) {
+        down_search_end = down_search_start + 2 * CH_LEN;
+        if (down_search_end > n) down_search_end = n;
+    }
+    int down_len = (int)(down_search_end - down_search_start);
+    int down_rel = ch_detect_template(s + down_search_start, down_len, 1, threshold, &down_corr);
+    if (down_rel < 0) return 0;
+    int down_pos = down_rel + (int)down_search_start;
+    out6[5] = down_corr;
+    float T = 500.0f / 1000.0f;
+    float chirp_rate = (2700.0f - 300.0f) / T;
+    float cfo_to_samples = 48000.0f / chirp_rate;
+    int expected_gap = CH_LEN + CH_GAP;
+    int actual_gap = down_pos - up_pos;
+    float gap_error = (float)(actual_gap - expected_gap);
+    float cfo = gap_error / (2.0f * cfo_to_samples);
+    out6[3] = cfo;
+    if (fabsf(cfo) > 100.0f) return 0;
+    float up_correction = cfo * cfo_to_samples;
+    float down_correction = -cfo * cfo_to_samples;
+    out6[1] = (float)(int)roundf((float)up_pos + up_correction);
+    out6[2] = (float)(int)roundf((float)down_pos + down_correction);
+    out6[0] = 1.f;
+    return 1;
+}

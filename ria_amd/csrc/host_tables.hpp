@@ -562,6 +562,51 @@ inline std::vector<float> build_zc_preamble(int root) {
     return out;
 }
 
+// ---------------------------------------------------------------- dual chirp (sync::ChirpSync)
+// chirp_sync.hpp:853-900 (phases, templates, energies), :61-108 (generate), fft.cpp:83-87 (twiddles)
+constexpr int kChirpLen = 24000, kChirpGap = 4800, kChirpFft = 131072;
+inline float chirp_phase(float t, bool down) {
+    const float T = 500.0f / 1000.0f, k = (2700.0f - 300.0f) / T;
+    const float inner = down ? (2700.0f * t - 0.5f * k * t * t) : (300.0f * t + 0.5f * k * t * t);
+    return static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(inner));
+}
+struct ChirpTables {
+    std::vector<float> tmpl;      // [4][24000] up sin, up cos, down sin, down cos
+    float energy[2] = {0, 0};
+    std::vector<float> tw;        // [65536][2]
+};
+inline ChirpTables build_chirp_tables() {
+    ChirpTables t;
+    t.tmpl.resize(static_cast<size_t>(4) * kChirpLen);
+    for (int d = 0; d < 2; ++d) {
+        float e = 0.0f;
+        for (int i = 0; i < kChirpLen; ++i) {
+            const float ph = chirp_phase(static_cast<float>(i) / 48000.0f, d == 1);
+            const float sn = sinf_glibc(ph);
+            t.tmpl[static_cast<size_t>(2 * d) * kChirpLen + i] = sn;
+            t.tmpl[static_cast<size_t>(2 * d + 1) * kChirpLen + i] = cosf_glibc(ph);
+            e += sn * sn;
+        }
+        t.energy[d] = e;
+    }
+    t.tw.resize(static_cast<size_t>(kChirpFft));
+    for (int k = 0; k < kChirpFft / 2; ++k) {
+        const float angle = static_cast<float>(static_cast<double>(-2.0f) * 3.14159265358979323846 * static_cast<double>(k) / static_cast<double>(kChirpFft));
+        t.tw[2 * k] = cosf_glibc(angle);
+        t.tw[2 * k + 1] = sinf_glibc(angle);
+    }
+    return t;
+}
+inline std::vector<float> build_chirp_preamble() {
+    std::vector<float> out(static_cast<size_t>(2 * kChirpLen + 2 * kChirpGap), 0.0f);
+    for (int i = 0; i < kChirpLen; ++i) {
+        const float t = static_cast<float>(i) / 48000.0f;
+        out[i] = 0.5f * sinf_glibc(chirp_phase(t, false));
+        out[kChirpLen + kChirpGap + i] = 0.5f * sinf_glibc(chirp_phase(t, true));
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------- RX gather (both de-interleavers folded)
 inline int channel_interleaver_step(int n, int total) {  // ldpc_decoder.cpp:552-577
     auto gcd = [](int a, int b) { while (b) { int t = b; b = a % b; a = t; } return a; };

@@ -40,6 +40,10 @@ struct ria_gpu {
     void* d_gather = nullptr; void* d_gather_nochan = nullptr;
     void* d_crc_bit = nullptr; void* d_crc_init = nullptr;
     void* d_zc_ref = nullptr;
+    // dual-chirp acquisition: tables (built at first use) and the per-chunk workspace
+    void* d_ch_tw = nullptr; void* d_ch_tmpl = nullptr; void* d_ch_tmpl_fft = nullptr; float ch_energy[2] = {0, 0};
+    void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
+    int ch_chunk = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
     void* d_demod_const = nullptr;
     void* d_tx_const = nullptr;
@@ -347,7 +351,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
-                    h->d_crc_bit, h->d_crc_init, h->d_zc_ref, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
+                    h->d_crc_bit, h->d_crc_init, h->d_zc_ref, h->d_ch_tw, h->d_ch_tmpl, h->d_ch_tmpl_fft, h->d_ch_w1, h->d_ch_w2, h->d_ch_mag, h->d_ch_cum, h->d_ch_st, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
                     h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -754,6 +758,113 @@ int ria_gpu_sync_zc_batch(ria_gpu_handle h, const float* samples_dev, int64_t st
 int ria_gpu_zc_preamble(ria_gpu_handle h, int root, float* out_host, int max_n) {
     if (!h || !out_host) return RIA_ERR_INVALID;
     std::vector<float> p = build_zc_preamble(root);
+    if (static_cast<int>(p.size()) > max_n) return -static_cast<int>(p.size());
+    std::memcpy(out_host, p.data(), p.size() * sizeof(float));
+    return static_cast<int>(p.size());
+}
+
+// forward or inverse 131072-point FFT of the active buffers of a chunk (see sync_kernels.hip.h)
+static void chirp_fft_forward(const ChirpArgs& A, int chunk, hipStream_t s, bool real_input, bool product) {
+    const dim3 g16(kChFft / 16 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
+    if (real_input) hipLaunchKernelGGL((chirp_fft_pass<4, 0, 1, false>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+    else hipLaunchKernelGGL((chirp_fft_pass<4, 0, 2, false>), g16, blk, 0, s, A, static_cast<const float2*>(A.w2), A.w1);
+    hipLaunchKernelGGL((chirp_fft_pass<4, 4, 0, false>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+    hipLaunchKernelGGL((chirp_fft_pass<4, 8, 0, false>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+    if (product) hipLaunchKernelGGL((chirp_fft_pass<5, 12, 3, false>), g32, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+    else hipLaunchKernelGGL((chirp_fft_pass<5, 12, 0, false>), g32, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+}
+static void chirp_fft_inverse_mag(const ChirpArgs& A, int chunk, hipStream_t s) {
+    const dim3 g16(kChFft / 16 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
+    hipLaunchKernelGGL((chirp_fft_pass<4, 0, 2, true>), g16, blk, 0, s, A, static_cast<const float2*>(A.w1), A.w2);
+    hipLaunchKernelGGL((chirp_fft_pass<4, 4, 0, true>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
+    hipLaunchKernelGGL((chirp_fft_pass<4, 8, 0, true>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
+    hipLaunchKernelGGL((chirp_fft_pass<5, 12, 4, true>), g32, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
+}
+__global__ void chirp_template_stage_kernel(const float* tmpl, int down, float2* dst, ChirpBufState* st) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { st[0].active = 1; st[0].win_start = 0; st[0].win_len = kChFft; }
+    if (i >= kChFft) return;
+    // complex template cos + j*sin, zero padded (chirp_sync.hpp:589-594)
+    dst[i] = (i < kChLen) ? make_float2(tmpl[(2 * down + 1) * kChLen + i], tmpl[(2 * down) * kChLen + i]) : make_float2(0.f, 0.f);
+}
+__global__ void chirp_template_conj_kernel(const float2* src, float2* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kChFft) dst[i] = make_float2(src[i].x, -src[i].y);
+}
+
+static int chirp_prepare(ria_gpu_handle h, int chunk, hipStream_t s) {
+    hipError_t e;
+#define C_TRY(expr) if ((e = (expr)) != hipSuccess) return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e))
+    if (chunk > h->ch_chunk) {
+        for (void** p : {&h->d_ch_w1, &h->d_ch_w2, &h->d_ch_mag, &h->d_ch_cum, &h->d_ch_st}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        const size_t c = static_cast<size_t>(chunk);
+        C_TRY(hipMalloc(&h->d_ch_w1, c * kChFft * sizeof(float2)));
+        C_TRY(hipMalloc(&h->d_ch_w2, c * kChFft * sizeof(float2)));
+        C_TRY(hipMalloc(&h->d_ch_mag, c * kChFft * sizeof(float)));
+        C_TRY(hipMalloc(&h->d_ch_cum, c * (kChFft + 1) * sizeof(float)));
+        C_TRY(hipMalloc(&h->d_ch_st, c * sizeof(ChirpBufState)));
+        h->ch_chunk = chunk;
+    }
+    if (!h->d_ch_tw) {
+        ChirpTables t = build_chirp_tables();
+        C_TRY(upload(&h->d_ch_tw, t.tw));
+        C_TRY(upload(&h->d_ch_tmpl, t.tmpl));
+        h->ch_energy[0] = t.energy[0]; h->ch_energy[1] = t.energy[1];
+        C_TRY(hipMalloc(&h->d_ch_tmpl_fft, static_cast<size_t>(2) * kChFft * sizeof(float2)));
+        // conj(FFT(template)) with the same butterflies the signal goes through (chirp_sync.hpp:573-623)
+        ChirpArgs A{};
+        A.n_buffers = 1; A.tw = static_cast<const float2*>(h->d_ch_tw); A.w1 = static_cast<float2*>(h->d_ch_w1);
+        A.w2 = static_cast<float2*>(h->d_ch_w2); A.st = static_cast<ChirpBufState*>(h->d_ch_st);
+        for (int d = 0; d < 2; ++d) {
+            hipLaunchKernelGGL(chirp_template_stage_kernel, dim3(kChFft / 256), dim3(256), 0, s, static_cast<const float*>(h->d_ch_tmpl), d, A.w2, A.st);
+            chirp_fft_forward(A, 1, s, false, false);
+            hipLaunchKernelGGL(chirp_template_conj_kernel, dim3(kChFft / 256), dim3(256), 0, s, static_cast<const float2*>(A.w1),
+                               static_cast<float2*>(h->d_ch_tmpl_fft) + static_cast<size_t>(d) * kChFft);
+        }
+        C_TRY(hipGetLastError());
+    }
+#undef C_TRY
+    return RIA_OK;
+}
+
+int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                             float threshold, ria_chirp_result* out_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_buffers == 0) return RIA_OK;
+    if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || stride < buf_len)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_chirp_batch: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // chunk size: 3.5 MiB of workspace per buffer; 64 buffers = 224 MiB stays within the 256 MiB Infinity Cache
+    const int chunk = std::min(n_buffers, 64);
+    int rc = chirp_prepare(h, chunk, s);
+    if (rc != RIA_OK) return rc;
+    ChirpArgs A{};
+    A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.threshold = threshold;
+    A.tw = static_cast<const float2*>(h->d_ch_tw); A.tmpl_fft = static_cast<const float2*>(h->d_ch_tmpl_fft);
+    A.tmpl = static_cast<const float*>(h->d_ch_tmpl); A.tmpl_energy[0] = h->ch_energy[0]; A.tmpl_energy[1] = h->ch_energy[1];
+    A.w1 = static_cast<float2*>(h->d_ch_w1); A.w2 = static_cast<float2*>(h->d_ch_w2); A.mag = static_cast<float*>(h->d_ch_mag);
+    A.cum = static_cast<float*>(h->d_ch_cum); A.st = static_cast<ChirpBufState*>(h->d_ch_st); A.out = out_dev;
+    for (int first = 0; first < n_buffers; first += chunk) {
+        const int nb = std::min(chunk, n_buffers - first);
+        A.first = first; A.n_buffers = nb;
+        for (int down = 0; down < 2; ++down) {
+            A.down = down;
+            hipLaunchKernelGGL(chirp_window_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(chirp_cumsum_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
+            chirp_fft_forward(A, nb, s, true, true);
+            chirp_fft_inverse_mag(A, nb, s);
+            hipLaunchKernelGGL(chirp_peak_kernel, dim3(nb), dim3(256), 0, s, A);
+            if (down) hipLaunchKernelGGL(chirp_td_kernel, dim3(nb), dim3(64), 0, s, A);
+        }
+        hipLaunchKernelGGL(chirp_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_chirp_preamble(ria_gpu_handle h, float* out_host, int max_n) {
+    if (!h || !out_host) return RIA_ERR_INVALID;
+    std::vector<float> p = build_chirp_preamble();
     if (static_cast<int>(p.size()) > max_n) return -static_cast<int>(p.size());
     std::memcpy(out_host, p.data(), p.size() * sizeof(float));
     return static_cast<int>(p.size());

@@ -201,4 +201,298 @@ __global__ __launch_bounds__(256) void zc_detect_kernel(ZcArgs A) {
     }
 }
 
+
+// =====================================================================================================
+// Dual-chirp acquisition: sync::ChirpSync::detectDualChirp (src/sync/chirp_sync.hpp:352-512) for a batch
+// of capture buffers, bit-exact.
+//
+// The reference correlates with a 24 000-sample complex chirp through a 131 072-point FFT
+// (detectChirpTemplateFFT :627-712: FFT(signal) * conj(FFT(template)) -> IFFT -> |.| normalised by a
+// sliding energy -> first maximum) for the up-chirp over the whole buffer and again for the down-chirp
+// over a window placed after the up-chirp.  Its FFT is the in-tree radix-2 DIT (src/dsp/fft.cpp:96-128).
+// A float result does not depend on the ORDER in which independent butterflies are evaluated, only on
+// each butterfly's own arithmetic, so the 17 stages are regrouped here into four register-resident
+// passes (4+4+4+5 stages; every thread runs a complete 2^G-point butterfly network on 2^G strided
+// elements) with the twiddles of fft.cpp:83-87:
+//   pass 1  gathers the bit-reversed input with COALESCED reads (thread t takes inputs t + m*N/16; they
+//           all land in output block bitrev(t)) — real samples, zero padding and window offset folded in;
+//   pass 4  of the forward transform multiplies by the stored conj(FFT(template)) on the way out;
+//   pass 4  of the inverse transform scales by 1/N and writes |corr| only.
+// The working set of one buffer (2 x 1 MiB complex + 0.5 MiB) is meant to stay in L2 / Infinity Cache:
+// the host loops over chunks of buffers small enough for that.
+// The sliding-energy normalisation uses a float running sum over the window (cumsum_energy :668-672):
+// serial by definition, so it is one LANE per buffer; the peak search is one workgroup per buffer.
+// Short down-chirp windows (< 48 000 samples) take the reference's time-domain path (:759-817).
+constexpr int kChLen = 24000, kChGap = 4800, kChFft = 131072, kChLog = 17;
+
+struct ChirpBufState {      // per buffer, device memory
+    int active;             // 1: this stage runs the FFT path, 2: time-domain path, 0: nothing to do
+    int win_start, win_len; // window of the current stage (up: whole buffer)
+    int pos;                // detection of the current stage (-1: none)
+    float corr;
+    int up_pos; float up_corr;
+};
+struct ChirpArgs {
+    const float* samples; long long stride; int buf_len; int n_buffers; int first;   // chunk = buffers [first, first+n_buffers)
+    float threshold;
+    const float2* tw;          // [65536]
+    const float2* tmpl_fft;    // [2][131072] conj(FFT(template)): up, down
+    const float* tmpl;         // [4][24000] up sin, up cos, down sin, down cos
+    float tmpl_energy[2];
+    float2* w1; float2* w2;    // [chunk][131072]
+    float* mag;                // [chunk][131072]
+    float* cum;                // [chunk][131073]
+    ChirpBufState* st;         // [chunk]
+    ria_chirp_result* out;     // [all buffers]
+    int down;                  // stage: 0 up, 1 down
+};
+
+__device__ __forceinline__ float2 ch_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ void ch_bfly(float2& a, float2& b, float2 w) {  // fft.cpp:113-117
+    const float2 t = ch_cmul(w, b);
+    b = make_float2(a.x - t.x, a.y - t.y);
+    a = make_float2(a.x + t.x, a.y + t.y);
+}
+__device__ __forceinline__ int ch_bitrev(int v, int bits) { return static_cast<int>(__brev(static_cast<unsigned>(v)) >> (32 - bits)); }
+
+// stage setup: up = whole buffer; down = window after the detected up-chirp (chirp_sync.hpp:430-452)
+__global__ void chirp_window_kernel(ChirpArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.n_buffers) return;
+    ChirpBufState& s = A.st[b];
+    const int n = A.buf_len;
+    if (!A.down) {
+        s.up_pos = -1; s.up_corr = 0.0f; s.pos = -1; s.corr = 0.0f;
+        s.win_start = 0; s.win_len = n;
+        s.active = (n >= 2 * kChLen + kChGap) ? 1 : 0;   // :372-376 (the up search always takes the FFT path)
+        ria_chirp_result o; o.success = 0; o.up_chirp_start = -1; o.down_chirp_start = -1; o.cfo_hz = 0.f; o.up_correlation = 0.f;
+        o.down_correlation = 0.f; o.reserved[0] = 0; o.reserved[1] = 0;
+        A.out[A.first + b] = o;
+        return;
+    }
+    s.up_pos = s.pos; s.up_corr = s.corr;
+    const bool had = s.active != 0;
+    s.active = 0;
+    if (had) A.out[A.first + b].up_correlation = s.up_corr;
+    if (!had || s.up_pos < 0) return;
+    const long long up = s.up_pos;
+    const long long start = up + kChLen / 2, expected = up + kChLen + kChGap, min_len = 2 * kChLen + 1000;
+    long long end = (expected + 10000 + kChLen > start + min_len) ? expected + 10000 + kChLen : start + min_len;
+    if (end > n) end = n;
+    if (start >= n) return;
+    if (end <= start + kChLen) { end = start + 2 * kChLen; if (end > n) end = n; }
+    s.win_start = static_cast<int>(start); s.win_len = static_cast<int>(end - start);
+    s.pos = -1; s.corr = 0.0f;
+    if (s.win_len < kChLen) { s.active = 0; return; }            // detectChirpTemplate :722-725 -> {-1, 0}
+    s.active = (s.win_len >= 2 * kChLen) ? 1 : 2;
+}
+
+// cumsum_energy[i+1] = cumsum_energy[i] + s[i]^2 (chirp_sync.hpp:668-672): one lane per buffer
+__global__ __launch_bounds__(64) void chirp_cumsum_kernel(ChirpArgs A) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.n_buffers) return;
+    const ChirpBufState s = A.st[b];
+    if (s.active != 1) return;
+    const float* x = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
+    float* cum = A.cum + static_cast<size_t>(b) * (kChFft + 1);
+    const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
+    float c = 0.0f;
+    cum[0] = 0.0f;
+    int i = 0;
+    for (; i + 8 <= fft_in; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[i + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { c = c + v[q] * v[q]; cum[i + q + 1] = c; }
+    }
+    for (; i < fft_in; ++i) { const float v = x[i]; c = c + v * v; cum[i + 1] = c; }
+}
+
+// One pass of the 131072-point radix-2 DIT FFT: stages S0+1 .. S0+G on 2^G elements per thread.
+// MODE 0: in place on w.   MODE 1: first pass, real input window (zero padded) -> dst.
+// MODE 2: first pass, complex src -> dst.   MODE 3: in place + multiply by tmpl on the way out (last forward).
+// MODE 4: last inverse pass: scale 1/N, write |.| to mag.
+template <int G, int S0, int MODE, bool INV>
+__global__ __launch_bounds__(256) void chirp_fft_pass(ChirpArgs A, const float2* __restrict__ src_all, float2* __restrict__ dst_all) {
+    constexpr int R = 1 << G;
+    const int b = blockIdx.y;
+    const ChirpBufState s = A.st[b];
+    if (s.active != 1) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;    // < N / R
+    float2* dst = dst_all + static_cast<size_t>(b) * kChFft;
+    float2 x[R];
+    int idx0, stridej;     // element j lives at idx0 + j*stridej in the DIT-ordered array
+    int lo = 0;
+    if constexpr (S0 == 0) {
+        constexpr int TB = kChLog - G;
+        const int hi = ch_bitrev(t, TB);
+        idx0 = hi * R; stridej = 1;
+        if constexpr (MODE == 1) {
+            const float* in = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
+            const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int n_in = m * (kChFft / R) + t;
+                x[ch_bitrev(m, G)] = make_float2(n_in < fft_in ? in[n_in] : 0.0f, 0.0f);
+            }
+        } else {
+            const float2* in = src_all + static_cast<size_t>(b) * kChFft;
+#pragma unroll
+            for (int m = 0; m < R; ++m) x[ch_bitrev(m, G)] = in[m * (kChFft / R) + t];
+        }
+    } else {
+        lo = t & ((1 << S0) - 1);
+        const int hi = t >> S0;
+        idx0 = lo + (hi << (S0 + G)); stridej = 1 << S0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = dst[idx0 + j * stridej];
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const int half = 1 << u, sidx = S0 + u + 1;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if ((j & half) == 0) {
+                const int k = lo + ((j & (half - 1)) << S0);
+                float2 w = A.tw[k << (kChLog - sidx)];
+                if (INV) w.y = -w.y;
+                ch_bfly(x[j], x[j + half], w);
+            }
+        }
+    }
+    if constexpr (MODE == 3) {
+        const float2* tf = A.tmpl_fft + static_cast<size_t>(A.down) * kChFft;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { const int i = idx0 + j * stridej; dst[i] = ch_cmul(x[j], tf[i]); }
+    } else if constexpr (MODE == 4) {
+        float* mag = A.mag + static_cast<size_t>(b) * kChFft;
+        const float scale = 1.0f / static_cast<float>(kChFft);
+#pragma unroll
+        for (int j = 0; j < R; ++j) mag[idx0 + j * stridej] = hypotf_glibc(x[j].x * scale, x[j].y * scale);
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) dst[idx0 + j * stridej] = x[j];
+    }
+}
+
+// first maximum of |corr[pos]| / sqrt(sig_energy * tmpl_energy) over pos < search_len (:677-693)
+__global__ __launch_bounds__(256) void chirp_peak_kernel(ChirpArgs A) {
+    __shared__ float sv[4]; __shared__ int si[4];
+    const int b = blockIdx.x;
+    ChirpBufState& s = A.st[b];
+    if (s.active != 1) return;
+    const float* mag = A.mag + static_cast<size_t>(b) * kChFft;
+    const float* cum = A.cum + static_cast<size_t>(b) * (kChFft + 1);
+    const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
+    const int search_len = fft_in - kChLen;
+    const float te = A.tmpl_energy[A.down];
+    float best = 0.0f; int bp = -1;
+    for (int pos = threadIdx.x; pos < search_len; pos += 256) {
+        const float se = cum[pos + kChLen] - cum[pos];
+        const float denom = fsqrt(se * te);
+        const float nc = (denom > 1e-10f) ? fdiv(mag[pos], denom) : 0.0f;
+        if (nc > best) { best = nc; bp = pos; }     // ascending pos within the thread: first maximum kept
+    }
+    float v = (bp >= 0) ? best : -1.0f; int idx = bp;
+    wave_argmax_first(v, idx);
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = -1.0f; int bi = -1;
+        for (int w = 0; w < 4; ++w) if (sv[w] > bv || (sv[w] == bv && si[w] >= 0 && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        const float corr = (bi >= 0) ? bv : 0.0f;
+        s.corr = corr;
+        s.pos = (bi >= 0 && !(corr < A.threshold)) ? bi : -1;
+    }
+}
+
+// time-domain path of detectChirpTemplate (:759-817) for short windows: one workgroup per buffer,
+// one lane per candidate position (every correlation is a left-to-right sum over 24 000 samples)
+__device__ inline float chirp_td_corr(const float* x, int n, int offset, const float* tsin, const float* tcos, float te) {  // :829-851
+    if (offset < 0 || offset + kChLen > n) return 0.0f;
+    float ci = 0.0f, cq = 0.0f, e = 0.0f;
+    const float* p = x + offset;
+    for (int i = 0; i < kChLen; ++i) {
+        const float v = p[i];
+        ci += v * tcos[i];
+        cq += v * tsin[i];
+        e += v * v;
+    }
+    const float denom = fsqrt(e * te);
+    if (denom < 1e-10f) return 0.0f;
+    return fdiv(fsqrt(ci * ci + cq * cq), denom);
+}
+__global__ __launch_bounds__(64) void chirp_td_kernel(ChirpArgs A) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    ChirpBufState& s = A.st[b];
+    if (s.active != 2) return;
+    const float* x = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
+    const int n = s.win_len, search_len = n - kChLen;
+    const float* tsin = A.tmpl + static_cast<size_t>(2 * A.down) * kChLen;
+    const float* tcos = tsin + kChLen;
+    const float te = A.tmpl_energy[A.down];
+    float best = 0.0f; int best_pos = -1;
+    const int n_coarse = (search_len + 47) / 48;
+    for (int base = 0; base < n_coarse; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < n_coarse;
+        float c = chirp_td_corr(x, n, valid ? k * 48 : 0, tsin, tcos, te);
+        float v = valid ? c : -1.0f; int idx = k * 48;
+        wave_argmax_first(v, idx);
+        if (v > best) { best = v; best_pos = idx; }
+    }
+    int pos_out = -1;
+    if (!(best_pos < 0 || best < A.threshold * 0.3f)) {
+        const int fine_start = best_pos - 48 < 0 ? 0 : best_pos - 48;
+        const int fine_end = best_pos + 48 > search_len ? search_len : best_pos + 48;
+        for (int base = fine_start; base <= fine_end; base += 64) {
+            const int p = base + lane;
+            const bool valid = p <= fine_end;
+            float c = chirp_td_corr(x, n, valid ? p : 0, tsin, tcos, te);
+            float v = valid ? c : -1.0f; int idx = p;
+            wave_argmax_first(v, idx);
+            if (v > best) { best = v; best_pos = idx; }
+        }
+        if (best_pos > 0 && best_pos < search_len - 1) {
+            const float cc = chirp_td_corr(x, n, best_pos + (lane == 0 ? -1 : 1), tsin, tcos, te);   // lanes 0, 1 matter
+            const float c0 = __shfl(cc, 0), c1 = best, c2 = __shfl(cc, 1);
+            const float denom = 2.0f * (c0 - 2.0f * c1 + c2);
+            if (fabs_(denom) > 1e-10f) {
+                float delta = fdiv(c0 - c2, denom);
+                const float lo = (1.0f < delta) ? 1.0f : delta;
+                delta = (-1.0f < lo) ? lo : -1.0f;
+                best_pos = static_cast<int>(__builtin_roundf(static_cast<float>(best_pos) + delta));
+            }
+        }
+        pos_out = (best >= A.threshold) ? best_pos : -1;
+    }
+    if (lane == 0) { s.corr = best; s.pos = pos_out; }
+}
+
+// CFO and position correction from the two detections (:454-509)
+__global__ void chirp_finish_kernel(ChirpArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.n_buffers) return;
+    const ChirpBufState s = A.st[b];
+    if (s.active == 0 || s.pos < 0) return;
+    ria_chirp_result o = A.out[A.first + b];
+    const int up_pos = s.up_pos, down_pos = s.pos + s.win_start;
+    o.down_correlation = s.corr;
+    const float T = fdiv(500.0f, 1000.0f);
+    const float chirp_rate = fdiv(2700.0f - 300.0f, T);
+    const float cfo_to_samples = fdiv(48000.0f, chirp_rate);
+    const int expected_gap = kChLen + kChGap, actual_gap = down_pos - up_pos;
+    const float gap_error = static_cast<float>(actual_gap - expected_gap);
+    const float cfo = fdiv(gap_error, 2.0f * cfo_to_samples);
+    o.cfo_hz = cfo;
+    if (!(fabs_(cfo) > 100.0f)) {
+        const float up_corr = cfo * cfo_to_samples, down_corr = -cfo * cfo_to_samples;
+        o.up_chirp_start = static_cast<int>(__builtin_roundf(static_cast<float>(up_pos) + up_corr));
+        o.down_chirp_start = static_cast<int>(__builtin_roundf(static_cast<float>(down_pos) + down_corr));
+        o.success = 1;
+    }
+    A.out[A.first + b] = o;
+}
+
 }  // namespace ria

@@ -173,6 +173,25 @@ class RxEngine:
             raise capi.RiaError("zc_preamble: buffer too small")
         return out[:n].copy()
 
+    CHIRP_RESULT = np.dtype([("success", "<i4"), ("up_chirp_start", "<i4"), ("down_chirp_start", "<i4"), ("cfo_hz", "<f4"),
+                             ("up_correlation", "<f4"), ("down_correlation", "<f4"), ("reserved", "<i4", 2)])
+
+    def sync_chirp(self, buffers, threshold=0.15):
+        """ChirpSync::detectDualChirp over a batch: buffers float32 [n, buf_len] on the device -> structured array."""
+        n, buf_len = buffers.shape
+        assert buffers.dtype == torch.float32 and buffers.is_contiguous()
+        out = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_sync_chirp_batch(self.h, _ptr(buffers), buf_len, buf_len, n, float(threshold),
+                                                      _ptr(out), _stream_ptr()))
+        return self._status_array(out, self.CHIRP_RESULT)
+
+    def chirp_preamble(self):
+        out = np.zeros(60000, np.float32)
+        n = self.lib.ria_gpu_chirp_preamble(self.h, out.ctypes.data, len(out))
+        if n < 0:
+            raise capi.RiaError("chirp_preamble: buffer too small")
+        return out[:n].copy()
+
     def debug_math(self, op, a, b=None):
         out = torch.empty_like(a)
         self._check(self.lib.ria_gpu_debug_math(self.h, op, _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream_ptr()))

@@ -122,3 +122,27 @@ def test_zc_sync_oracle_matches_reference_golden(oracle, golden):
     for x, p, r in zip(g["buffers"], g["params"], g["results"]):
         out = oracle.zc_detect(x, 0.3, int(p[4]), float(p[5]))
         assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (p, out, r)
+
+
+def _chirp_cases(golden, chirp):
+    """Rebuilds the chirp fixture's buffers from its recipe (seeded numpy noise); skips if this numpy
+    no longer reproduces them (checksums are part of the fixture)."""
+    import zlib
+    import gen_golden
+    g = golden("chirp_sync")
+    if zlib.crc32(chirp.tobytes()) != int(g["preamble_crc"][0]):
+        pytest.fail("dual-chirp preamble differs from the reference's")
+    out = []
+    for i, case in enumerate(g["cases"]):
+        x, crc = gen_golden.chirp_buffer(chirp, (int(case[0]), int(case[1]), float(case[2]), float(case[3])), i)
+        if crc != int(g["buffer_crc"][i]):
+            pytest.skip("numpy no longer reproduces the recorded noise stream; regenerate with oracle/gen_golden.py")
+        out.append((x, g["results"][i]))
+    return out
+
+
+def test_chirp_sync_oracle_matches_reference_golden(oracle, golden):
+    """sync::ChirpSync (chirp_sync.hpp): preamble audio (by checksum) and every DualChirpResult field."""
+    for x, r in _chirp_cases(golden, oracle.chirp_generate()):
+        out = oracle.chirp_detect(x, 0.15)
+        assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (len(x), out, r)
