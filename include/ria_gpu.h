@@ -225,6 +225,40 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
  * returns the sample count or -needed. */
 int ria_gpu_chirp_preamble(ria_gpu_handle h, float* out_host, int max_n);
 
+/* ---- MC-DPSK demodulator (src/psk/multi_carrier_dpsk.hpp) and HARQ chase combine (src/fec/chase_cache.cpp)
+ * ria_gpu_mcdpsk_demod_batch replaces MultiCarrierDPSKDemodulator as MCDPSKWaveform::process drives it after
+ * an external chirp detection (setChirpDetected + process, multi_carrier_dpsk.hpp:797-896): each frame is
+ * training (8 x 512) + reference (512) + data symbols, frame f at samples_dev + f*stride; per-frame CFO (Hz)
+ * and initial CFO phase (rad) may be NULL (0).  LLRs come out as demodulateSoft returns them
+ * ((frame_samples/512 - 9)/spreading * carriers * bits_per_symbol values), bit-identical. */
+typedef struct ria_mcdpsk_config {
+    int32_t num_carriers;      /* 3..20 (reference default 8; MC-DPSK modes use 10) */
+    int32_t bits_per_symbol;   /* 1 DBPSK, 2 DQPSK */
+    int32_t spreading;         /* 1, 2 or 4 (SpreadingMode) */
+    int32_t reserved;
+} ria_mcdpsk_config;
+typedef struct ria_mcdpsk_status {
+    float cfo_hz;                  /* getEstimatedCFO() after the frame */
+    float fading_index;            /* getFadingIndex() */
+    float freq_fading_index;
+    float temporal_fading_index;
+    float training_cfo_residual;   /* processTraining's estimate (not applied after an external chirp) */
+    int32_t n_llr;
+    int32_t valid_symbols;
+    int32_t reserved;
+} ria_mcdpsk_status;               /* 32 bytes */
+int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const float* samples_dev, int64_t stride,
+                               int frame_samples, int n_frames, const float* cfo_hz_dev, const float* phase0_dev,
+                               float* llr_out_dev, int llr_stride, ria_mcdpsk_status* status_dev, void* stream);
+/* MultiCarrierDPSKModulator: generateTrainingSequence + generateReferenceSymbol + modulate(data) into a HOST
+ * buffer (multi_carrier_dpsk.hpp:141-281); returns the sample count or -needed.  Bit-identical audio. */
+int ria_gpu_mcdpsk_modulate_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data, int n_bytes,
+                                 float* out_host, int max_n);
+/* fec::ChaseCache::store arithmetic for n_cw codeword slots of 648 LLRs (chase_cache.cpp:27-88): count 0 ->
+ * copy, else add; skipped when decoded_dev[cw] != 0 or count >= 4.  stored_out_dev (nullable) gets 1/0. */
+int ria_gpu_chase_combine_batch(ria_gpu_handle h, float* acc_dev, int32_t* count_dev, const uint8_t* decoded_dev,
+                                const float* soft_dev, int n_cw, uint8_t* stored_out_dev, void* stream);
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

@@ -49,6 +49,34 @@ def chirp_buffer(chirp, case, idx):
     return x, zlib.crc32(x.tobytes())
 
 
+MCDPSK_CASES = [(10, 1, 1, 20.0, 0.0, 0.0), (10, 1, 1, 0.0, 0.0, 0.0), (10, 2, 1, 8.0, 0.0, 0.0), (10, 1, 2, -3.0, 0.0, 0.0),
+                (10, 1, 4, -6.0, 0.0, 0.0), (8, 2, 1, 15.0, 6.5, 0.4), (10, 1, 1, 5.0, -12.0, -1.1), (5, 2, 2, 6.0, 0.0, 0.0)]
+
+
+def mcdpsk_frame(R_or_O, case, idx):
+    """Noisy (and optionally CFO-shifted) training+ref+data frame of one 81-byte codeword, float32."""
+    nc, bps, sp, snr_db, cfo, ph0 = case
+    rng = np.random.default_rng(7000 + idx)
+    data = rng.integers(0, 256, 81, dtype=np.uint8)
+    tx = R_or_O.mcdpsk_modulate(nc, bps, sp, data)
+    x = tx.astype(np.float64) + rng.normal(0, np.sqrt(np.mean(tx.astype(np.float64) ** 2)) * 10 ** (-snr_db / 20.0), len(tx))
+    if cfo:
+        from scipy.signal import hilbert
+        x = np.real(hilbert(x) * np.exp(2j * np.pi * cfo * np.arange(len(x)) / 48000.0))
+    if idx == 3:
+        x[-6 * 512:] *= 0.02      # trailing near-silence: exercises the valid_symbols trimming
+    return data, tx, x.astype(np.float32)
+
+
+def mcdpsk_fixture(R):
+    rec = {"cases": np.array(MCDPSK_CASES, np.float32)}
+    for i, case in enumerate(MCDPSK_CASES):
+        data, tx, x = mcdpsk_frame(R, case, i)
+        llr, aux = R.mcdpsk_demod(case[0], case[1], case[2], x, float(case[4]), float(case[5]))
+        rec[f"data_{i}"] = data; rec[f"tx_crc_{i}"] = np.array([__import__("zlib").crc32(tx.tobytes())], np.uint32); rec[f"rx_{i}"] = x; rec[f"llr_{i}"] = llr; rec[f"aux_{i}"] = aux
+    return rec
+
+
 def chirp_fixture(R):
     chirp = R.chirp_generate()
     rec = {"preamble_crc": np.array([__import__("zlib").crc32(chirp.tobytes())], np.uint32), "cases": np.array(CHIRP_CASES, np.float32)}
@@ -160,6 +188,7 @@ def main():
     # reference's DualChirpResult
     rec = chirp_fixture(R)
     np.savez_compressed(os.path.join(OUT, "chirp_sync.npz"), **rec)
+    np.savez_compressed(os.path.join(OUT, "mcdpsk.npz"), **mcdpsk_fixture(R))
     print("done ->", OUT)
     return 0
 

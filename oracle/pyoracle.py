@@ -81,6 +81,8 @@ class Oracle:
         L.ro_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
         L.ro_chirp_generate.argtypes = [_f, C.c_int]
         L.ro_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
+        L.ro_mcdpsk_modulate.argtypes = [C.c_int, C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
+        L.ro_mcdpsk_demod.argtypes = [C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _f, C.c_int, _f]
         self._geoms = {}
         self._codes = {}
 
@@ -100,6 +102,22 @@ class Oracle:
         out = np.zeros(60000, np.float32)
         n = self.lib.ro_chirp_generate(fp(out), len(out))
         return out[:n].copy()
+
+    def mcdpsk_modulate(self, nc, bps, spreading, data):
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.zeros(600000, np.float32)
+        n = self.lib.ro_mcdpsk_modulate(nc, bps, spreading, up(data), len(data), fp(out), len(out))
+        assert n > 0
+        return out[:n].copy()
+
+    def mcdpsk_demod(self, nc, bps, spreading, samples, cfo_hz=0.0, phase0=0.0):
+        """-> (llr float32[n], aux float32[4] {cfo, fading, freq fading, temporal fading})"""
+        x = np.ascontiguousarray(samples, np.float32)
+        llr = np.zeros(8192, np.float32)
+        aux = np.zeros(4, np.float32)
+        n = self.lib.ro_mcdpsk_demod(nc, bps, spreading, fp(x), len(x), cfo_hz, phase0, fp(llr), len(llr), fp(aux))
+        assert n > 0, n
+        return llr[:n].copy(), aux
 
     def chirp_detect(self, samples, threshold=0.15):
         """-> float32[6] {success, up_start, down_start, cfo_hz, up_corr, down_corr}"""
@@ -220,6 +238,8 @@ class Ref:
         L.ref_detect_data_sync.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _i, _f, _i]
         L.ref_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
         L.ref_chirp_generate.argtypes = [_f, C.c_int]
+        L.ref_mcdpsk_modulate.argtypes = [C.c_int, C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
+        L.ref_mcdpsk_demod.argtypes = [C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _f, C.c_int, _f]
         L.ref_zc_generate.argtypes = [C.c_int, _f, C.c_int]
         L.ref_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
         L.ref_quiet()
@@ -239,6 +259,21 @@ class Ref:
         out = np.zeros(6, np.float32)
         self.lib.ref_chirp_detect(fp(x), len(x), threshold, fp(out))
         return out
+
+    def mcdpsk_modulate(self, nc, bps, spreading, data):
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.zeros(600000, np.float32)
+        n = self.lib.ref_mcdpsk_modulate(nc, bps, spreading, up(data), len(data), fp(out), len(out))
+        assert n > 0
+        return out[:n].copy()
+
+    def mcdpsk_demod(self, nc, bps, spreading, samples, cfo_hz=0.0, phase0=0.0):
+        x = np.ascontiguousarray(samples, np.float32)
+        llr = np.zeros(8192, np.float32)
+        aux = np.zeros(4, np.float32)
+        n = self.lib.ref_mcdpsk_demod(nc, bps, spreading, fp(x), len(x), cfo_hz, phase0, fp(llr), len(llr), fp(aux))
+        assert n > 0, n
+        return llr[:n].copy(), aux
 
     def zc_detect(self, samples, threshold=0.3, root_mask=15, known_cfo=0.0):
         x = np.ascontiguousarray(samples, np.float32)

@@ -43,6 +43,7 @@
 #include "sim/hf_channel.hpp"
 #include "sync/chirp_sync.hpp"
 #include "sync/zc_sync.hpp"
+#include "psk/multi_carrier_dpsk.hpp"
 #define private public
 #include "waveform/ofdm_chirp_waveform.hpp"
 #undef private
@@ -313,6 +314,47 @@ int ref_zc_detect(const float* samples, int n, float thr, int root_mask, float k
     out7[5] = r.snr_estimate;
     out7[6] = static_cast<float>(r.root_detected);
     return r.detected ? 1 : 0;
+}
+
+// MultiCarrierDPSK (src/psk/multi_carrier_dpsk.hpp): modulator output training+ref+data, and the
+// demodulator driven exactly as MCDPSKWaveform::process drives it after an external chirp detection
+// (mc_dpsk_waveform.cpp:322-332 -> processGotChirp, multi_carrier_dpsk.hpp:797-896).
+static MultiCarrierDPSKConfig mc_config(int carriers, int bps, int spreading) {
+    MultiCarrierDPSKConfig c;
+    c.num_carriers = carriers;
+    c.bits_per_symbol = bps;
+    c.spreading_mode = spreading == 4 ? SpreadingMode::TIME_4X : spreading == 2 ? SpreadingMode::TIME_2X : SpreadingMode::NONE;
+    return c;
+}
+int ref_mcdpsk_modulate(int carriers, int bps, int spreading, const uint8_t* data, int n_bytes, float* out, int max_n) {
+    ref_quiet();
+    MultiCarrierDPSKModulator m(mc_config(carriers, bps, spreading));
+    Samples tr = m.generateTrainingSequence();
+    Samples rf = m.generateReferenceSymbol();
+    Samples dt = m.modulate(Bytes(data, data + n_bytes));
+    int n = static_cast<int>(tr.size() + rf.size() + dt.size());
+    if (n > max_n) return -n;
+    std::memcpy(out, tr.data(), tr.size() * sizeof(float));
+    std::memcpy(out + tr.size(), rf.data(), rf.size() * sizeof(float));
+    std::memcpy(out + tr.size() + rf.size(), dt.data(), dt.size() * sizeof(float));
+    return n;
+}
+// aux4 = {estimated cfo after the frame, fading index, frequency fading index, temporal fading index}
+int ref_mcdpsk_demod(int carriers, int bps, int spreading, const float* samples, int n, float cfo_hz, float phase0,
+                     float* llr_out, int max_llr, float* aux4) {
+    ref_quiet();
+    MultiCarrierDPSKDemodulator d(mc_config(carriers, bps, spreading));
+    d.setChirpDetected(cfo_hz);
+    d.setCFOWithPhase(cfo_hz, phase0);
+    bool ready = d.process(SampleSpan(samples, n));
+    if (!ready) return -1;
+    float fading = d.getFadingIndex(), ffi = d.getFrequencyFadingIndex(), tfi = d.getTemporalFadingIndex(), cfo = d.getEstimatedCFO();
+    std::vector<float> sb = d.getSoftBits();
+    int m = static_cast<int>(sb.size());
+    if (m > max_llr) return -m;
+    std::memcpy(llr_out, sb.data(), sb.size() * sizeof(float));
+    aux4[0] = cfo; aux4[1] = fading; aux4[2] = ffi; aux4[3] = tfi;
+    return m;
 }
 
 }  // extern "C"

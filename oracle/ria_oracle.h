@@ -109,5 +109,12 @@ int ro_zc_detect(const float* rx, int n, float threshold, int root_mask, float k
  * out6 = {success, up_chirp_start, down_chirp_start, cfo_hz, up_correlation, down_correlation} */
 int ro_chirp_generate(float* out, int max_n);
 int ro_chirp_detect(const float* s, int n, float threshold, float* out6);
+/* MultiCarrierDPSK (src/psk/multi_carrier_dpsk.hpp): training + reference + data audio, and the demodulator chain
+ * of processGotChirp after an external chirp detection.  aux4 = {cfo, fading, frequency fading, temporal fading}. */
+int ro_mcdpsk_modulate(int nc, int bps, int spreading, const uint8_t* data, int n_bytes, float* out, int max_n);
+int ro_mcdpsk_demod(int nc, int bps, int spreading, const float* samples, int n, float cfo_hz, float phase0,
+                    float* llr_out, int max_llr, float* aux4);
+/* fec::ChaseCache::store arithmetic for one codeword slot (src/fec/chase_cache.cpp:27-88) */
+int ro_chase_store(float* existing, int* combine_count, int decoded, const float* soft);
 
 #endif

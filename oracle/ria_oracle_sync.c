@@ -431,3 +431,346 @@ int ro_chirp_detect(const float* s, int n, float threshold, float* out6) { /* de
     out6[0] = 1.f;
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------------ MC-DPSK
+ * src/psk/multi_carrier_dpsk.hpp: modulator :126-323 (generateTrainingSequence, generateReferenceSymbol,
+ * modulate), demodulator: applyCFOCorrection :901-926 (HilbertTransform, src/dsp/filters.cpp:266-317),
+ * demodulateOneSymbol :931-946, processTraining :473-505, setReference :507-518, demodulateSoft :520-736,
+ * fading indices :404-437; driven as processGotChirp :797-896 with an external chirp detection.
+ * HARQ chase combine: src/fec/chase_cache.cpp:27-88 (store).
+ */
+#define MC_SPS 512
+#define MC_TRAIN 8
+#define MC_MAXC 20
+static const float kMcFs = 48000.0f;
+static const float kPiF = (float)M_PI;
+
+static void mc_freqs(int nc, float* f) { /* getCarrierFreqs :66-78 */
+    if (nc == 1) { f[0] = (500.0f + 2500.0f) / 2.0f; return; }
+    float spacing = (2500.0f - 500.0f) / (nc - 1);
+    for (int i = 0; i < nc; ++i) f[i] = 500.0f + i * spacing;
+}
+typedef struct { float re, im; } mcf;
+static mcf mc_polar(float rho, float theta) { mcf r = {rho * cosf(theta), rho * sinf(theta)}; return r; }
+static mcf mc_mul(mcf a, mcf b) { mcf r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; return r; }
+static mcf mc_conj(mcf a) { mcf r = {a.re, -a.im}; return r; }
+
+int ro_mcdpsk_modulate(int nc, int bps, int spreading, const uint8_t* data, int n_bytes, float* out, int max_n) {
+    float freqs[MC_MAXC];
+    mcf prev[MC_MAXC];
+    mc_freqs(nc, freqs);
+    int bits_per_sym = nc * bps;
+    int n_bits = n_bytes * 8;
+    int n_data_sym = (n_bits + bits_per_sym - 1) / bits_per_sym;
+    int total = (MC_TRAIN + 1 + n_data_sym * spreading) * MC_SPS;
+    if (total > max_n) return -total;
+    memset(out, 0, sizeof(float) * (size_t)total);
+    /* training :141-175 */
+    for (int sym = 0; sym < MC_TRAIN; ++sym)
+        for (int c = 0; c < nc; ++c) {
+            float phase_offset = (float)((c * sym) * M_PI / 2.0f);
+            mcf ts = mc_polar(1.0f, phase_offset);
+            float phase_inc = (float)(2.0f * M_PI * freqs[c] / kMcFs);
+            for (int i = 0; i < MC_SPS; ++i) {
+                float t = i * phase_inc;
+                mcf m = mc_mul(ts, mc_polar(1.0f, t));
+                out[sym * MC_SPS + i] += m.re / nc;
+            }
+        }
+    /* reference :178-199 */
+    float* ref = out + MC_TRAIN * MC_SPS;
+    for (int c = 0; c < nc; ++c) {
+        float phase_inc = (float)(2.0f * M_PI * freqs[c] / kMcFs);
+        mcf rs = {1.0f, 0.0f};
+        prev[c] = rs;
+        for (int i = 0; i < MC_SPS; ++i) {
+            float t = i * phase_inc;
+            mcf m = mc_mul(rs, mc_polar(1.0f, t));
+            ref[i] += m.re / nc;
+        }
+    }
+    /* data :202-281 */
+    float* dat = ref + MC_SPS;
+    float* one = (float*)malloc(sizeof(float) * MC_SPS);
+    int bit_idx = 0;
+    for (int ds = 0; ds < n_data_sym; ++ds) {
+        memset(one, 0, sizeof(float) * MC_SPS);
+        for (int c = 0; c < nc; ++c) {
+            int sb = 0;
+            for (int b = 0; b < bps; ++b) {
+                int bit = (bit_idx < n_bits) ? (data[bit_idx >> 3] >> (7 - (bit_idx & 7))) & 1 : 0;
+                ++bit_idx;
+                sb = (sb << 1) | bit;
+            }
+            float phase_change;
+            if (bps == 2) {
+                const float ph[4] = {(float)(M_PI / 4), (float)(3 * M_PI / 4), (float)(-3 * M_PI / 4), (float)(-M_PI / 4)};
+                phase_change = ph[sb];
+            } else {
+                phase_change = sb ? (float)M_PI : 0.0f;
+            }
+            mcf cur = mc_mul(prev[c], mc_polar(1.0f, phase_change));
+            float a = hypotf(cur.re, cur.im);
+            cur.re /= a; cur.im /= a;
+            prev[c] = cur;
+            float phase_inc = (float)(2.0f * M_PI * freqs[c] / kMcFs);
+            for (int i = 0; i < MC_SPS; ++i) {
+                float t = i * phase_inc;
+                mcf m = mc_mul(cur, mc_polar(1.0f, t));
+                one[i] += m.re / nc;
+            }
+        }
+        for (int rep = 0; rep < spreading; ++rep) memcpy(dat + (size_t)(ds * spreading + rep) * MC_SPS, one, sizeof(float) * MC_SPS);
+    }
+    free(one);
+    return total;
+}
+
+static mcf mc_demod_symbol(const float* s, float freq) { /* :931-946 */
+    float phase_inc = (float)(2.0f * M_PI * freq / kMcFs);
+    float sr = 0.0f, si = 0.0f, phase = 0.0f;
+    for (int i = 0; i < MC_SPS; ++i) {
+        mcf m = mc_polar(1.0f, -phase);
+        sr += s[i] * m.re;
+        si += s[i] * m.im;
+        phase += phase_inc;
+    }
+    mcf r = {sr / (float)MC_SPS, si / (float)MC_SPS};
+    return r;
+}
+
+static void mc_apply_cfo(float* x, int n, float cfo_hz, float phase0) { /* :901-926 + filters.cpp:266-317 */
+    if (fabsf(cfo_hz) < 0.01f || n < 128) return;
+    enum { TAPS = 127, M = 63 };
+    float coeff[TAPS];
+    for (int k = 0; k < TAPS; ++k) {
+        int kk = k - M;
+        if (kk == 0) coeff[k] = 0;
+        else if (kk % 2 != 0) coeff[k] = (float)(2.0f / (M_PI * kk));
+        else coeff[k] = 0;
+        float w = (float)(2.0f * M_PI * k / (TAPS - 1));
+        coeff[k] *= 0.42f - 0.5f * cosf(w) + 0.08f * cosf(2.0f * w);
+    }
+    float* ar = (float*)malloc(sizeof(float) * (size_t)n);
+    float* ai = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float q = 0;
+        for (int k = 0; k < TAPS; ++k) {
+            float v = (i - k >= 0) ? x[i - k] : 0.0f;
+            q += coeff[k] * v;
+        }
+        ar[i] = (i - M >= 0) ? x[i - M] : 0.0f;
+        ai[i] = q;
+    }
+    float phase_inc = (float)(-2.0f * M_PI * cfo_hz / kMcFs);
+    float phase = phase0;
+    for (int i = 0; i < n; ++i) {
+        float rc = cosf(phase), rs = sinf(phase);
+        x[i] = ar[i] * rc - ai[i] * rs;
+        phase += phase_inc;
+        if (phase > M_PI) phase = (float)(phase - 2.0f * M_PI);
+        if (phase < -M_PI) phase = (float)(phase + 2.0f * M_PI);
+    }
+    free(ar); free(ai);
+}
+
+/* aux4 = {cfo after the frame, fading index, frequency fading index, temporal fading index}; returns #LLRs */
+int ro_mcdpsk_demod(int nc, int bps, int spreading, const float* samples, int n, float cfo_hz, float phase0,
+                    float* llr_out, int max_llr, float* aux4) {
+    float freqs[MC_MAXC];
+    mcf prev[MC_MAXC];
+    mc_freqs(nc, freqs);
+    const int local_preamble = (MC_TRAIN + 1) * MC_SPS;
+    int data_samples;
+    if (n > local_preamble) data_samples = n - local_preamble;
+    else { int bpsym = nc * bps; data_samples = ((648 + bpsym - 1) / bpsym) * MC_SPS; }
+    if (n < local_preamble + data_samples) return -1;
+    float* x = (float*)malloc(sizeof(float) * (size_t)n);
+    memcpy(x, samples, sizeof(float) * (size_t)n);
+    float cfo = cfo_hz;
+    if (fabsf(cfo) > 0.1f) { mc_apply_cfo(x, n, cfo, phase0); cfo = 0.0f; }
+    /* processTraining (its estimate is discarded after an external chirp detection, :857-861) */
+    float saved_cfo = cfo;
+    {
+        float sum = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            mcf s0 = mc_demod_symbol(x, freqs[c]), s1 = mc_demod_symbol(x + MC_SPS, freqs[c]);
+            float expected_phase = (float)((c * 1 - c * 0) * M_PI / 2.0f);
+            mcf ed = mc_polar(1.0f, expected_phase);
+            mcf ad = mc_mul(s1, mc_conj(s0));
+            mcf er = mc_mul(ad, mc_conj(ed));
+            sum += atan2f(er.im, er.re);
+        }
+        float avg = sum / nc;
+        float symbol_duration = MC_SPS / kMcFs;
+        float residual = (float)(avg / (2.0f * M_PI * symbol_duration));
+        cfo += residual;
+        float lo = (50.0f < cfo) ? 50.0f : cfo;
+        cfo = (-50.0f < lo) ? lo : -50.0f;
+    }
+    cfo = saved_cfo;
+    /* setReference */
+    const float* rsym = x + MC_TRAIN * MC_SPS;
+    for (int c = 0; c < nc; ++c) {
+        mcf p = mc_demod_symbol(rsym, freqs[c]);
+        float a = hypotf(p.re, p.im);
+        if (a > 0.001f) { float a2 = hypotf(p.re, p.im); p.re /= a2; p.im /= a2; } else { p.re = 1.0f; p.im = 0.0f; }
+        prev[c] = p;
+    }
+    /* demodulateSoft */
+    const float* data = x + local_preamble;
+    int num_rx = data_samples / MC_SPS;
+    int nds = num_rx / spreading;
+    if (nds < 1) nds = 1;
+    int n_llr = nds * nc * bps;
+    if (n_llr > max_llr) { free(x); return -n_llr; }
+    float mag_sum[MC_MAXC] = {0}, mag_sq[MC_MAXC] = {0};
+    float* sym_total = (float*)calloc((size_t)nds, sizeof(float));
+    float* cph = (float*)malloc(sizeof(float) * (size_t)nds * nc);
+    float* cmag = (float*)calloc((size_t)nds * nc, sizeof(float));
+    float noise_sum = 0.0f;
+    int noise_count = 0;
+    for (int ds = 0; ds < nds; ++ds)
+        for (int c = 0; c < nc; ++c) {
+            mcf comb = {0.0f, 0.0f};
+            for (int rep = 0; rep < spreading; ++rep) {
+                int rs = ds * spreading + rep;
+                if (rs >= num_rx) break;
+                mcf cur = mc_demod_symbol(data + (size_t)rs * MC_SPS, freqs[c]);
+                comb.re += cur.re; comb.im += cur.im;
+            }
+            comb.re /= (float)spreading; comb.im /= (float)spreading;
+            float mag = hypotf(comb.re, comb.im);
+            cmag[ds * nc + c] = mag;
+            sym_total[ds] += mag;
+            mag_sum[c] += mag;
+            mag_sq[c] += mag * mag;
+            mcf nrm;
+            if (mag > 0.0001f) { nrm.re = comb.re / mag; nrm.im = comb.im / mag; } else { nrm.re = 1.0f; nrm.im = 0.0f; }
+            mcf diff = mc_mul(nrm, mc_conj(prev[c]));
+            prev[c] = nrm;
+            float phase = atan2f(diff.im, diff.re);
+            cph[ds * nc + c] = phase;
+            float pe;
+            if (bps == 2) {
+                float shifted = phase - kPiF / 4.0f;
+                float nearest = roundf(shifted / (kPiF / 2.0f));
+                float ideal = nearest * kPiF / 2.0f + kPiF / 4.0f;
+                pe = phase - ideal;
+            } else {
+                float nearest = roundf(phase / kPiF);
+                float ideal = nearest * kPiF;
+                pe = phase - ideal;
+            }
+            while (pe > kPiF) pe -= 2.0f * kPiF;
+            while (pe < -kPiF) pe += 2.0f * kPiF;
+            noise_sum += pe * pe;
+            noise_count++;
+        }
+    int valid = nds;
+    if (nds >= 4) {
+        float ref_mag = 0.0f;
+        for (int s = 0; s < 4; ++s) ref_mag += sym_total[s];
+        ref_mag /= 4.0f;
+        if (ref_mag > 0.001f) {
+            float thr = ref_mag * 0.2f;
+            while (valid > 4 && sym_total[valid - 1] < thr) valid--;
+            if (valid < nds) {
+                for (int c = 0; c < nc; ++c) { mag_sum[c] = 0.0f; mag_sq[c] = 0.0f; }
+                for (int s = 0; s < valid; ++s)
+                    for (int c = 0; c < nc; ++c) { float m = cmag[s * nc + c]; mag_sum[c] += m; mag_sq[c] += m * m; }
+            }
+        }
+    }
+    float pnv = (noise_count > 0) ? noise_sum / noise_count : 0.5f;
+    pnv = (0.01f < pnv) ? pnv : 0.01f;                  /* std::max(0.01f, pnv) */
+    float scale = 2.0f * sqrtf(1.0f / pnv);
+    scale = (20.0f < scale) ? 20.0f : scale;            /* std::min(scale, 20.0f) */
+    float rel[MC_MAXC];
+    for (int c = 0; c < nc; ++c) rel[c] = 1.0f;
+    if (bps == 1 && valid > 0) {
+        float mean_mag[MC_MAXC];
+        float gsum = 0.0f;
+        int gcount = 0;
+        for (int c = 0; c < nc; ++c) {
+            float mean = mag_sum[c] / valid;
+            mean_mag[c] = mean;
+            if (mean > 1e-4f) { gsum += mean; gcount++; }
+        }
+        float gmean = (gcount > 0) ? gsum / gcount : 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            float mean = mean_mag[c];
+            if (mean <= 1e-4f || gmean <= 1e-4f) { rel[c] = 0.12f; continue; }
+            float mean_sq = mag_sq[c] / valid;
+            float var = mean_sq - mean * mean;
+            var = (0.0f < var) ? var : 0.0f;            /* std::max(0.0f, var) */
+            float cv = sqrtf(var) / (mean + 1e-6f);
+            float ratio = mean / gmean;
+            float t1 = (ratio < 1.25f) ? ratio : 1.25f; /* std::min(1.25f, ratio) */
+            float mw = (0.10f < t1) ? t1 : 0.10f;
+            float sw = 1.0f / (1.0f + 1.5f * cv);
+            float wd = 1.0f;
+            if (ratio < 0.20f) wd = 0.25f; else if (ratio < 0.35f) wd = 0.50f;
+            float w = mw * sw * wd;
+            float t2 = (w < 1.25f) ? w : 1.25f;
+            rel[c] = (0.12f < t2) ? t2 : 0.12f;
+        }
+    }
+    int o = 0;
+    for (int ds = 0; ds < nds; ++ds)
+        for (int c = 0; c < nc; ++c) {
+            float phase = cph[ds * nc + c];
+            float cs = scale * rel[c];
+            if (bps == 2) {
+                float sb0 = cs * sinf(phase), sb1 = cs * sinf(2.0f * phase);
+                float a = (sb0 < 20.0f) ? sb0 : 20.0f; llr_out[o++] = (-20.0f < a) ? a : -20.0f;
+                float b = (sb1 < 20.0f) ? sb1 : 20.0f; llr_out[o++] = (-20.0f < b) ? b : -20.0f;
+            } else {
+                float sb = cs * cosf(phase);
+                float a = (sb < 20.0f) ? sb : 20.0f; llr_out[o++] = (-20.0f < a) ? a : -20.0f;
+            }
+        }
+    /* fading indices :404-437, :705-733 */
+    float cmagn[MC_MAXC];
+    for (int c = 0; c < nc; ++c) cmagn[c] = (valid > 0) ? mag_sum[c] / valid : 0.0f;
+    float tfi = 0.0f;
+    if (valid >= 4) {
+        float cvsum = 0.0f;
+        int vc = 0;
+        for (int c = 0; c < nc; ++c) {
+            float mean = mag_sum[c] / valid;
+            if (mean < 0.001f) continue;
+            float mean_sq = mag_sq[c] / valid;
+            float var = mean_sq - mean * mean;
+            var = (0.0f < var) ? var : 0.0f;
+            float cv = sqrtf(var) / mean;
+            cvsum += cv;
+            vc++;
+        }
+        tfi = (vc > 0) ? cvsum / vc : 0.0f;
+    }
+    float ffi = 0.0f;
+    {
+        float sum = 0.0f;
+        for (int c = 0; c < nc; ++c) sum += cmagn[c];
+        float mean = sum / nc;
+        if (!(mean < 0.001f)) {
+            float vs = 0.0f;
+            for (int c = 0; c < nc; ++c) { float d = cmagn[c] - mean; vs += d * d; }
+            ffi = sqrtf(vs / nc) / mean;
+        }
+    }
+    aux4[0] = cfo; aux4[1] = ffi + 1.0f * tfi; aux4[2] = ffi; aux4[3] = tfi;
+    free(x); free(sym_total); free(cph); free(cmag);
+    return n_llr;
+}
+
+/* ChaseCacheEntry combine (chase_cache.cpp:27-88): count/decoded bookkeeping of ONE codeword slot */
+int ro_chase_store(float* existing, int* combine_count, int decoded, const float* soft) {
+    if (decoded) return 0;
+    if (*combine_count >= 4) return 0;
+    if (*combine_count == 0) { memcpy(existing, soft, sizeof(float) * 648); *combine_count = 1; return 1; }
+    for (int i = 0; i < 648; ++i) existing[i] += soft[i];
+    (*combine_count)++;
+    return 1;
+}

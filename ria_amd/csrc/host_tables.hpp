@@ -607,6 +607,107 @@ inline std::vector<float> build_chirp_preamble() {
     return out;
 }
 
+// ---------------------------------------------------------------- MC-DPSK (multi_carrier_dpsk.hpp)
+constexpr int kMcdSps = 512, kMcdTrain = 8;
+inline std::vector<float> mcdpsk_freqs(int nc) {   // getCarrierFreqs :66-78
+    std::vector<float> f(nc);
+    if (nc == 1) { f[0] = (500.0f + 2500.0f) / 2.0f; return f; }
+    const float spacing = (2500.0f - 500.0f) / (nc - 1);
+    for (int i = 0; i < nc; ++i) f[i] = 500.0f + i * spacing;
+    return f;
+}
+inline float mcdpsk_phase_inc(float freq) { return static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(freq) / static_cast<double>(48000.0f)); }
+// mixer[c][i] = std::polar(1.0f, -phase_i), phase_0 = 0, phase_{i+1} = phase_i + phase_inc (:931-946)
+inline std::vector<float> build_mcdpsk_mixer(int nc) {
+    std::vector<float> m(static_cast<size_t>(nc) * kMcdSps * 2);
+    const std::vector<float> fr = mcdpsk_freqs(nc);
+    for (int c = 0; c < nc; ++c) {
+        const float inc = mcdpsk_phase_inc(fr[c]);
+        float phase = 0.0f;
+        for (int i = 0; i < kMcdSps; ++i) {
+            m[(static_cast<size_t>(c) * kMcdSps + i) * 2] = 1.0f * cosf_glibc(-phase);
+            m[(static_cast<size_t>(c) * kMcdSps + i) * 2 + 1] = 1.0f * sinf_glibc(-phase);
+            phase += inc;
+        }
+    }
+    return m;
+}
+inline std::vector<float> build_hilbert127() {   // filters.cpp:266-291
+    const int taps = 127, M = 63;
+    std::vector<float> c(taps);
+    for (int n = 0; n < taps; ++n) {
+        const int k = n - M;
+        if (k == 0) c[n] = 0;
+        else if (k % 2 != 0) c[n] = static_cast<float>(static_cast<double>(2.0f) / (3.14159265358979323846 * k));
+        else c[n] = 0;
+        const float w = static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * n / (taps - 1));
+        c[n] *= 0.42f - 0.5f * cosf_glibc(w) + 0.08f * cosf_glibc(2.0f * w);
+    }
+    return c;
+}
+// training + reference + data audio (:141-281)
+inline std::vector<float> build_mcdpsk_frame(int nc, int bps, int spreading, const uint8_t* data, int n_bytes) {
+    const std::vector<float> fr = mcdpsk_freqs(nc);
+    const int bits_per_sym = nc * bps, n_bits = n_bytes * 8;
+    const int n_data_sym = (n_bits + bits_per_sym - 1) / bits_per_sym;
+    std::vector<float> out(static_cast<size_t>(kMcdTrain + 1 + n_data_sym * spreading) * kMcdSps, 0.0f);
+    auto cmulr = [](float ar, float ai, float br, float bi) { return ar * br - ai * bi; };   // real part of a*b
+    std::vector<float> pr(nc, 1.0f), pi(nc, 0.0f);
+    for (int sym = 0; sym < kMcdTrain; ++sym)
+        for (int c = 0; c < nc; ++c) {
+            const float po = static_cast<float>(static_cast<double>(c * sym) * 3.14159265358979323846 / static_cast<double>(2.0f));
+            const float tr = 1.0f * cosf_glibc(po), ti = 1.0f * sinf_glibc(po);
+            const float inc = mcdpsk_phase_inc(fr[c]);
+            for (int i = 0; i < kMcdSps; ++i) {
+                const float t = i * inc;
+                out[static_cast<size_t>(sym) * kMcdSps + i] += cmulr(tr, ti, 1.0f * cosf_glibc(t), 1.0f * sinf_glibc(t)) / nc;
+            }
+        }
+    float* ref = out.data() + static_cast<size_t>(kMcdTrain) * kMcdSps;
+    for (int c = 0; c < nc; ++c) {
+        const float inc = mcdpsk_phase_inc(fr[c]);
+        pr[c] = 1.0f; pi[c] = 0.0f;
+        for (int i = 0; i < kMcdSps; ++i) {
+            const float t = i * inc;
+            ref[i] += cmulr(1.0f, 0.0f, 1.0f * cosf_glibc(t), 1.0f * sinf_glibc(t)) / nc;
+        }
+    }
+    float* dat = ref + kMcdSps;
+    std::vector<float> one(kMcdSps);
+    int bit_idx = 0;
+    for (int ds = 0; ds < n_data_sym; ++ds) {
+        std::fill(one.begin(), one.end(), 0.0f);
+        for (int c = 0; c < nc; ++c) {
+            int sb = 0;
+            for (int b = 0; b < bps; ++b) {
+                const int bit = (bit_idx < n_bits) ? (data[bit_idx >> 3] >> (7 - (bit_idx & 7))) & 1 : 0;
+                ++bit_idx;
+                sb = (sb << 1) | bit;
+            }
+            float pc;
+            if (bps == 2) {
+                const float ph[4] = {static_cast<float>(3.14159265358979323846 / 4), static_cast<float>(3 * 3.14159265358979323846 / 4),
+                                     static_cast<float>(-3 * 3.14159265358979323846 / 4), static_cast<float>(-3.14159265358979323846 / 4)};
+                pc = ph[sb];
+            } else {
+                pc = sb ? static_cast<float>(3.14159265358979323846) : 0.0f;
+            }
+            const float dr = 1.0f * cosf_glibc(pc), di = 1.0f * sinf_glibc(pc);
+            float cr = pr[c] * dr - pi[c] * di, ci = pr[c] * di + pi[c] * dr;
+            const float a = hypotf_glibc(cr, ci);
+            cr /= a; ci /= a;
+            pr[c] = cr; pi[c] = ci;
+            const float inc = mcdpsk_phase_inc(fr[c]);
+            for (int i = 0; i < kMcdSps; ++i) {
+                const float t = i * inc;
+                one[i] += cmulr(cr, ci, 1.0f * cosf_glibc(t), 1.0f * sinf_glibc(t)) / nc;
+            }
+        }
+        for (int rep = 0; rep < spreading; ++rep) std::copy(one.begin(), one.end(), dat + static_cast<size_t>(ds * spreading + rep) * kMcdSps);
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------- RX gather (both de-interleavers folded)
 inline int channel_interleaver_step(int n, int total) {  // ldpc_decoder.cpp:552-577
     auto gcd = [](int a, int b) { while (b) { int t = b; b = a % b; a = t; } return a; };

@@ -1,0 +1,301 @@
+// ria_amd/csrc/mcdpsk_kernels.hip.h — multi-carrier DPSK demodulator and the HARQ
+// chase combine (a19).
+//
+// mcdpsk_demod_kernel: MultiCarrierDPSKDemodulator driven as MCDPSKWaveform::process drives it after an
+// external chirp detection (mc_dpsk_waveform.cpp:322-332 -> processGotChirp, multi_carrier_dpsk.hpp:797-896):
+// applyCFOCorrection (:901-926, Hilbert FIR src/dsp/filters.cpp:266-317) -> processTraining (:473-505, its
+// estimate is reported but not applied, :857-861) -> setReference (:507-518) -> demodulateSoft (:520-736),
+// one workgroup per frame, bit-exact:
+//   * every (symbol, carrier) correlation is a left-to-right float sum over 512 samples against the
+//     carrier's mixer e^{-j*phase_i}; phase_i is a float recurrence that restarts at every symbol, so the
+//     mixer is a per-carrier table built once on the host; one LANE per (symbol, carrier);
+//   * the differential chain, the noise/magnitude statistics and the reliability weights are short ordered
+//     loops -> one lane (or one lane per carrier), values parked in LDS;
+//   * LLRs: one lane per (data symbol, carrier);
+//   * CFO correction: the 127-tap Hilbert FIR is one lane per output sample (ordered 127-term sum); the
+//     rotation phase is a wrapped float recurrence over the whole frame -> one lane walks it while the
+//     other waves filter.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ria_gpu.h"
+#include "devmath.h"
+
+namespace ria {
+
+constexpr int kMcSps = 512, kMcTrain = 8, kMcMaxCarriers = 20, kMcHilbertTaps = 127;
+
+struct McArgs {
+    const float* samples; long long stride; int frame_samples; int n_frames; int first;
+    int nc, bps, spreading;
+    const float* cfo; const float* phase0;
+    const float2* mixer;       // [nc][512]
+    const float* hilbert;      // [127]
+    float* ws;                 // [chunk][2][frame_samples] corrected samples | rotation phases
+    float* llr; int llr_stride;
+    ria_mcdpsk_status* status;
+};
+
+__device__ __forceinline__ float2 mc_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int nc = A.nc, bps = A.bps, sp = A.spreading, n = A.frame_samples;
+    const int local_preamble = (kMcTrain + 1) * kMcSps;
+    const int data_samples = n - local_preamble;
+    const int num_rx = data_samples / kMcSps;
+    int nds = num_rx / sp;
+    if (nds < 1) nds = 1;
+    const int n_sym = 3 + num_rx;                 // training 0, training 1, reference, data...
+    // LDS carve-up
+    float2* mix = reinterpret_cast<float2*>(smem);                         // [nc][512]
+    float2* Y = mix + nc * kMcSps;                                         // [n_sym][nc]
+    float* cph = reinterpret_cast<float*>(Y + n_sym * nc);                 // [nds][nc]
+    float* cmag = cph + nds * nc;                                          // [nds][nc]
+    float* pe2 = cmag + nds * nc;                                          // [nds][nc]
+    float* rel = pe2 + nds * nc;                                           // [nc] + scalars
+    float* scal = rel + kMcMaxCarriers;                                    // [8]
+    const float* x = A.samples + static_cast<long long>(A.first + f) * A.stride;
+    for (int i = tid; i < nc * kMcSps; i += 256) mix[i] = A.mixer[i];
+    // ---- CFO correction (:901-926)
+    float cfo = A.cfo ? A.cfo[A.first + f] : 0.0f;
+    if (fabs_(cfo) > 0.1f && !(fabs_(cfo) < 0.01f) && n >= 128) {
+        float* xc = A.ws + static_cast<size_t>(f) * 2 * n;
+        float* ph = xc + n;
+        if (tid == 0) {
+            const float phase_inc = static_cast<float>(static_cast<double>(-2.0f) * 3.14159265358979323846 * static_cast<double>(cfo) / static_cast<double>(48000.0f));
+            float phase = A.phase0 ? A.phase0[A.first + f] : 0.0f;
+            for (int i = 0; i < n; ++i) {
+                ph[i] = phase;
+                phase += phase_inc;
+                if (static_cast<double>(phase) > 3.14159265358979323846) phase = static_cast<float>(static_cast<double>(phase) - static_cast<double>(2.0f) * 3.14159265358979323846);
+                if (static_cast<double>(phase) < -3.14159265358979323846) phase = static_cast<float>(static_cast<double>(phase) + static_cast<double>(2.0f) * 3.14159265358979323846);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            float q = 0.0f;
+            for (int k = 0; k < kMcHilbertTaps; ++k) {
+                const float v = (i - k >= 0) ? x[i - k] : 0.0f;
+                q += A.hilbert[k] * v;
+            }
+            const float re = (i - 63 >= 0) ? x[i - 63] : 0.0f;
+            const float p = ph[i];
+            xc[i] = re * cosf_glibc(p) - q * sinf_glibc(p);
+        }
+        __syncthreads();
+        x = xc;
+        cfo = 0.0f;
+    }
+    __syncthreads();
+    // ---- correlations (:931-946): task (symbol s, carrier c); s = 0,1 training, 2 reference, 3.. data
+    for (int task = tid; task < n_sym * nc; task += 256) {
+        const int s = task / nc, c = task - s * nc;
+        const int sym_index = (s < 2) ? s : (s == 2 ? kMcTrain : kMcTrain + 1 + (s - 3));
+        const float* xs = x + sym_index * kMcSps;
+        const float2* m = mix + c * kMcSps;
+        float sr = 0.0f, si = 0.0f;
+        for (int i = 0; i < kMcSps; ++i) {
+            const float v = xs[i];
+            const float2 w = m[i];
+            sr += v * w.x;
+            si += v * w.y;
+        }
+        Y[task] = make_float2(fdiv(sr, static_cast<float>(kMcSps)), fdiv(si, static_cast<float>(kMcSps)));
+    }
+    __syncthreads();
+    // ---- per-carrier differential chain (setReference + demodulateSoft pass 1), one lane per carrier
+    if (tid < nc) {
+        const int c = tid;
+        float2 prev = Y[2 * nc + c];
+        const float a = hypotf_glibc(prev.x, prev.y);
+        if (a > 0.001f) { const float a2 = hypotf_glibc(prev.x, prev.y); prev = make_float2(fdiv(prev.x, a2), fdiv(prev.y, a2)); }
+        else prev = make_float2(1.0f, 0.0f);
+        const float kPi = 3.14159274101257324f;   // (float)M_PI
+        for (int ds = 0; ds < nds; ++ds) {
+            float2 comb = make_float2(0.0f, 0.0f);
+            for (int rep = 0; rep < sp; ++rep) {
+                const int rs = ds * sp + rep;
+                if (rs >= num_rx) break;
+                const float2 cur = Y[(3 + rs) * nc + c];
+                comb.x += cur.x; comb.y += cur.y;
+            }
+            comb.x = fdiv(comb.x, static_cast<float>(sp)); comb.y = fdiv(comb.y, static_cast<float>(sp));
+            const float mag = hypotf_glibc(comb.x, comb.y);
+            float2 nrm = (mag > 0.0001f) ? make_float2(fdiv(comb.x, mag), fdiv(comb.y, mag)) : make_float2(1.0f, 0.0f);
+            const float2 diff = mc_cmul(nrm, make_float2(prev.x, -prev.y));
+            prev = nrm;
+            const float phase = atan2f_glibc(diff.y, diff.x);
+            float pe;
+            if (bps == 2) {
+                const float shifted = phase - fdiv(kPi, 4.0f);
+                const float nearest = __builtin_roundf(fdiv(shifted, fdiv(kPi, 2.0f)));
+                const float ideal = fdiv(nearest * kPi, 2.0f) + fdiv(kPi, 4.0f);
+                pe = phase - ideal;
+            } else {
+                const float nearest = __builtin_roundf(fdiv(phase, kPi));
+                pe = phase - nearest * kPi;
+            }
+            while (pe > kPi) pe -= 2.0f * kPi;
+            while (pe < -kPi) pe += 2.0f * kPi;
+            cph[ds * nc + c] = phase; cmag[ds * nc + c] = mag; pe2[ds * nc + c] = pe * pe;
+        }
+    }
+    __syncthreads();
+    // ---- ordered statistics, processTraining, reliability weights: one lane
+    if (tid == 0) {
+        // processTraining (:473-505)
+        float psum = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            const float2 s0 = Y[c], s1 = Y[nc + c];
+            const float expected_phase = static_cast<float>(static_cast<double>(c) * 3.14159265358979323846 / static_cast<double>(2.0f));
+            const float2 ed = make_float2(1.0f * cosf_glibc(expected_phase), 1.0f * sinf_glibc(expected_phase));
+            const float2 ad = mc_cmul(s1, make_float2(s0.x, -s0.y));
+            const float2 er = mc_cmul(ad, make_float2(ed.x, -ed.y));
+            psum += atan2f_glibc(er.y, er.x);
+        }
+        const float avg = fdiv(psum, static_cast<float>(nc));
+        const float symbol_duration = fdiv(static_cast<float>(kMcSps), 48000.0f);
+        const float residual = static_cast<float>(static_cast<double>(avg) / (static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(symbol_duration)));
+        // statistics of demodulateSoft (:560-640)
+        float noise_sum = 0.0f;
+        for (int i = 0; i < nds * nc; ++i) noise_sum += pe2[i];
+        const int noise_count = nds * nc;
+        float mag_sum[kMcMaxCarriers], mag_sq[kMcMaxCarriers];
+        for (int c = 0; c < nc; ++c) { mag_sum[c] = 0.0f; mag_sq[c] = 0.0f; }
+        int valid = nds;
+        {
+            for (int ds = 0; ds < nds; ++ds)
+                for (int c = 0; c < nc; ++c) { const float m = cmag[ds * nc + c]; mag_sum[c] += m; mag_sq[c] += m * m; }
+            if (nds >= 4) {
+                auto sym_total = [&](int ds) { float t = 0.0f; for (int c = 0; c < nc; ++c) t += cmag[ds * nc + c]; return t; };
+                float ref_mag = 0.0f;
+                for (int s = 0; s < 4; ++s) ref_mag += sym_total(s);
+                ref_mag = fdiv(ref_mag, 4.0f);
+                if (ref_mag > 0.001f) {
+                    const float thr = ref_mag * 0.2f;
+                    while (valid > 4 && sym_total(valid - 1) < thr) valid--;
+                    if (valid < nds) {
+                        for (int c = 0; c < nc; ++c) { mag_sum[c] = 0.0f; mag_sq[c] = 0.0f; }
+                        for (int s = 0; s < valid; ++s)
+                            for (int c = 0; c < nc; ++c) { const float m = cmag[s * nc + c]; mag_sum[c] += m; mag_sq[c] += m * m; }
+                    }
+                }
+            }
+        }
+        float pnv = (noise_count > 0) ? fdiv(noise_sum, static_cast<float>(noise_count)) : 0.5f;
+        pnv = (0.01f < pnv) ? pnv : 0.01f;
+        float scale = 2.0f * fsqrt(fdiv(1.0f, pnv));
+        scale = (20.0f < scale) ? 20.0f : scale;
+        for (int c = 0; c < nc; ++c) rel[c] = 1.0f;
+        if (bps == 1 && valid > 0) {
+            float mean_mag[kMcMaxCarriers];
+            float gsum = 0.0f; int gcount = 0;
+            for (int c = 0; c < nc; ++c) {
+                const float mean = fdiv(mag_sum[c], static_cast<float>(valid));
+                mean_mag[c] = mean;
+                if (mean > 1e-4f) { gsum += mean; gcount++; }
+            }
+            const float gmean = (gcount > 0) ? fdiv(gsum, static_cast<float>(gcount)) : 0.0f;
+            for (int c = 0; c < nc; ++c) {
+                const float mean = mean_mag[c];
+                if (mean <= 1e-4f || gmean <= 1e-4f) { rel[c] = 0.12f; continue; }
+                const float mean_sq = fdiv(mag_sq[c], static_cast<float>(valid));
+                float var = mean_sq - mean * mean;
+                var = (0.0f < var) ? var : 0.0f;
+                const float cv = fdiv(fsqrt(var), mean + 1e-6f);
+                const float ratio = fdiv(mean, gmean);
+                const float t1 = (ratio < 1.25f) ? ratio : 1.25f;
+                const float mw = (0.10f < t1) ? t1 : 0.10f;
+                const float sw = fdiv(1.0f, 1.0f + 1.5f * cv);
+                float wd = 1.0f;
+                if (ratio < 0.20f) wd = 0.25f; else if (ratio < 0.35f) wd = 0.50f;
+                const float w = mw * sw * wd;
+                const float t2 = (w < 1.25f) ? w : 1.25f;
+                rel[c] = (0.12f < t2) ? t2 : 0.12f;
+            }
+        }
+        scal[0] = scale;
+        // fading indices (:404-437, :705-733)
+        float tfi = 0.0f;
+        if (valid >= 4) {
+            float cvsum = 0.0f; int vc = 0;
+            for (int c = 0; c < nc; ++c) {
+                const float mean = fdiv(mag_sum[c], static_cast<float>(valid));
+                if (mean < 0.001f) continue;
+                const float mean_sq = fdiv(mag_sq[c], static_cast<float>(valid));
+                float var = mean_sq - mean * mean;
+                var = (0.0f < var) ? var : 0.0f;
+                cvsum += fdiv(fsqrt(var), mean);
+                vc++;
+            }
+            tfi = (vc > 0) ? fdiv(cvsum, static_cast<float>(vc)) : 0.0f;
+        }
+        float ffi = 0.0f;
+        {
+            float cm[kMcMaxCarriers];
+            float sum = 0.0f;
+            for (int c = 0; c < nc; ++c) { cm[c] = (valid > 0) ? fdiv(mag_sum[c], static_cast<float>(valid)) : 0.0f; sum += cm[c]; }
+            const float mean = fdiv(sum, static_cast<float>(nc));
+            if (!(mean < 0.001f)) {
+                float vs = 0.0f;
+                for (int c = 0; c < nc; ++c) { const float d = cm[c] - mean; vs += d * d; }
+                ffi = fdiv(fsqrt(fdiv(vs, static_cast<float>(nc))), mean);
+            }
+        }
+        ria_mcdpsk_status st;
+        st.cfo_hz = cfo; st.fading_index = ffi + 1.0f * tfi; st.freq_fading_index = ffi; st.temporal_fading_index = tfi;
+        st.training_cfo_residual = residual; st.n_llr = nds * nc * bps; st.valid_symbols = valid; st.reserved = 0;
+        A.status[A.first + f] = st;
+    }
+    __syncthreads();
+    // ---- LLRs (:650-667)
+    const float scale = scal[0];
+    float* out = A.llr + static_cast<size_t>(A.first + f) * A.llr_stride;
+    for (int i = tid; i < nds * nc; i += 256) {
+        const int c = i % nc;
+        const float phase = cph[i];
+        const float cs = scale * rel[c];
+        if (bps == 2) {
+            const float sb0 = cs * sinf_glibc(phase), sb1 = cs * sinf_glibc(2.0f * phase);
+            const float a = (sb0 < 20.0f) ? sb0 : 20.0f, b = (sb1 < 20.0f) ? sb1 : 20.0f;
+            out[2 * i] = (-20.0f < a) ? a : -20.0f;
+            out[2 * i + 1] = (-20.0f < b) ? b : -20.0f;
+        } else {
+            const float sb = cs * cosf_glibc(phase);
+            const float a = (sb < 20.0f) ? sb : 20.0f;
+            out[i] = (-20.0f < a) ? a : -20.0f;
+        }
+    }
+}
+
+__host__ __device__ inline int mcdpsk_lds_bytes(int nc, int frame_samples, int spreading) {
+    const int num_rx = (frame_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
+    int nds = num_rx / spreading; if (nds < 1) nds = 1;
+    return nc * kMcSps * 8 + (3 + num_rx) * nc * 8 + 3 * nds * nc * 4 + (kMcMaxCarriers + 8) * 4 + 64;
+}
+
+// fec::ChaseCache::store for a batch of codeword slots (src/fec/chase_cache.cpp:27-88): first reception
+// copies, later ones add (LLR sum), at most 4 combines, decoded slots are left alone
+__global__ __launch_bounds__(256) void chase_combine_kernel(float* __restrict__ acc, int32_t* __restrict__ count,
+                                                            const uint8_t* __restrict__ decoded, const float* __restrict__ soft,
+                                                            int n_cw, uint8_t* __restrict__ stored) {
+    const int cw = blockIdx.x;
+    if (cw >= n_cw) return;
+    const int cnt = count[cw];
+    const bool skip = (decoded && decoded[cw]) || cnt >= 4;
+    __syncthreads();
+    if (!skip) {
+        float* a = acc + static_cast<size_t>(cw) * 648;
+        const float* s = soft + static_cast<size_t>(cw) * 648;
+        for (int i = threadIdx.x; i < 648; i += 256) a[i] = (cnt == 0) ? s[i] : a[i] + s[i];
+    }
+    if (threadIdx.x == 0) {
+        if (!skip) count[cw] = cnt + 1;
+        if (stored) stored[cw] = skip ? 0 : 1;
+    }
+}
+
+}  // namespace ria

@@ -25,6 +25,7 @@
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
 #include "sync_kernels.hip.h"
+#include "mcdpsk_kernels.hip.h"
 
 using namespace ria;
 
@@ -44,6 +45,8 @@ struct ria_gpu {
     void* d_ch_tw = nullptr; void* d_ch_tmpl = nullptr; void* d_ch_tmpl_fft = nullptr; float ch_energy[2] = {0, 0};
     void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
     int ch_chunk = 0;
+    // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
+    std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
     void* d_demod_const = nullptr;
     void* d_tx_const = nullptr;
@@ -355,6 +358,9 @@ void ria_gpu_destroy(ria_gpu_handle h) {
                     h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& kv : h->d_mc_mixer) if (kv.second) (void)hipFree(kv.second);
+    if (h->d_mc_hilbert) (void)hipFree(h->d_mc_hilbert);
+    if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
@@ -868,6 +874,81 @@ int ria_gpu_chirp_preamble(ria_gpu_handle h, float* out_host, int max_n) {
     if (static_cast<int>(p.size()) > max_n) return -static_cast<int>(p.size());
     std::memcpy(out_host, p.data(), p.size() * sizeof(float));
     return static_cast<int>(p.size());
+}
+
+static bool mcdpsk_config_ok(const ria_mcdpsk_config* c) {
+    return c && c->num_carriers >= 1 && c->num_carriers <= kMcMaxCarriers && (c->bits_per_symbol == 1 || c->bits_per_symbol == 2) &&
+           (c->spreading == 1 || c->spreading == 2 || c->spreading == 4);
+}
+
+int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const float* samples_dev, int64_t stride,
+                               int frame_samples, int n_frames, const float* cfo_hz_dev, const float* phase0_dev,
+                               float* llr_out_dev, int llr_stride, ria_mcdpsk_status* status_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_frames == 0) return RIA_OK;
+    if (!mcdpsk_config_ok(cfg) || !samples_dev || !llr_out_dev || !status_dev || n_frames < 0 || stride < frame_samples ||
+        frame_samples < (kMcTrain + 2) * kMcSps)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_demod_batch: bad arguments");
+    const int nc = cfg->num_carriers, num_rx = (frame_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
+    const int nds = std::max(1, num_rx / cfg->spreading);
+    if (llr_stride < nds * nc * cfg->bits_per_symbol) return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_demod_batch: llr_stride too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->d_mc_mixer.count(nc)) {
+        void* p = nullptr;
+        std::vector<float> m = build_mcdpsk_mixer(nc);
+        HIP_TRY(h, upload(&p, m));
+        h->d_mc_mixer[nc] = p;
+    }
+    if (!h->d_mc_hilbert) { std::vector<float> hc = build_hilbert127(); HIP_TRY(h, upload(&h->d_mc_hilbert, hc)); }
+    const int lds = mcdpsk_lds_bytes(nc, frame_samples, cfg->spreading);
+    if (lds > 160 * 1024) return fail(h, RIA_ERR_UNSUPPORTED, "ria_gpu_mcdpsk_demod_batch: frame too long for one workgroup's LDS");
+    static std::atomic<int> lds_opted{0};
+    if (lds > lds_opted.load()) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mcdpsk_demod_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        lds_opted.store(lds);
+    }
+    // CFO-corrected samples + rotation phases live in a workspace: chunks of frames when a CFO array is given
+    const int chunk = cfo_hz_dev ? std::min(n_frames, 1024) : n_frames;
+    if (cfo_hz_dev) {
+        const size_t need = static_cast<size_t>(chunk) * 2 * frame_samples;
+        if (need > h->mc_ws_floats) {
+            if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
+            h->d_mc_ws = nullptr; h->mc_ws_floats = 0;
+            HIP_TRY(h, hipMalloc(&h->d_mc_ws, need * sizeof(float)));
+            h->mc_ws_floats = need;
+        }
+    }
+    McArgs A{};
+    A.samples = samples_dev; A.stride = stride; A.frame_samples = frame_samples; A.nc = nc; A.bps = cfg->bits_per_symbol;
+    A.spreading = cfg->spreading; A.cfo = cfo_hz_dev; A.phase0 = phase0_dev; A.mixer = static_cast<const float2*>(h->d_mc_mixer[nc]);
+    A.hilbert = static_cast<const float*>(h->d_mc_hilbert); A.ws = static_cast<float*>(h->d_mc_ws); A.llr = llr_out_dev;
+    A.llr_stride = llr_stride; A.status = status_dev;
+    for (int first = 0; first < n_frames; first += chunk) {
+        A.first = first; A.n_frames = std::min(chunk, n_frames - first);
+        hipLaunchKernelGGL(mcdpsk_demod_kernel, dim3(A.n_frames), dim3(256), lds, s, A);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_mcdpsk_modulate_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data, int n_bytes,
+                                 float* out_host, int max_n) {
+    if (!h || !mcdpsk_config_ok(cfg) || !data || !out_host || n_bytes < 0) return RIA_ERR_INVALID;
+    std::vector<float> f = build_mcdpsk_frame(cfg->num_carriers, cfg->bits_per_symbol, cfg->spreading, data, n_bytes);
+    if (static_cast<int>(f.size()) > max_n) return -static_cast<int>(f.size());
+    std::memcpy(out_host, f.data(), f.size() * sizeof(float));
+    return static_cast<int>(f.size());
+}
+
+int ria_gpu_chase_combine_batch(ria_gpu_handle h, float* acc_dev, int32_t* count_dev, const uint8_t* decoded_dev,
+                                const float* soft_dev, int n_cw, uint8_t* stored_out_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_cw == 0) return RIA_OK;
+    if (!acc_dev || !count_dev || !soft_dev || n_cw < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_chase_combine_batch: bad arguments");
+    hipLaunchKernelGGL(chase_combine_kernel, dim3(n_cw), dim3(256), 0, static_cast<hipStream_t>(stream), acc_dev, count_dev, decoded_dev,
+                       soft_dev, n_cw, stored_out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
 }
 
 int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n, float* out_dev,

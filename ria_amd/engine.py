@@ -192,6 +192,39 @@ class RxEngine:
             raise capi.RiaError("chirp_preamble: buffer too small")
         return out[:n].copy()
 
+    MCDPSK_STATUS = np.dtype([("cfo_hz", "<f4"), ("fading_index", "<f4"), ("freq_fading_index", "<f4"),
+                              ("temporal_fading_index", "<f4"), ("training_cfo_residual", "<f4"), ("n_llr", "<i4"),
+                              ("valid_symbols", "<i4"), ("reserved", "<i4")])
+
+    def mcdpsk_demod(self, frames, carriers=10, bits_per_symbol=1, spreading=1, cfo_hz=None, phase0=None):
+        """MC-DPSK demodulator over a batch: frames float32 [n, (9 + symbols)*512] -> (llr [n, n_llr], status)."""
+        n, fs = frames.shape
+        assert frames.dtype == torch.float32 and frames.is_contiguous()
+        cfg = capi.McdpskConfig(carriers, bits_per_symbol, spreading, 0)
+        n_llr = max(1, ((fs - 9 * 512) // 512) // spreading) * carriers * bits_per_symbol
+        llr = torch.empty((n, n_llr), dtype=torch.float32, device=self.device)
+        st = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_mcdpsk_demod_batch(self.h, C.byref(cfg), _ptr(frames), fs, fs, n, _ptr(cfo_hz), _ptr(phase0),
+                                                        _ptr(llr), n_llr, _ptr(st), _stream_ptr()))
+        return llr, self._status_array(st, self.MCDPSK_STATUS)
+
+    def mcdpsk_modulate(self, data, carriers=10, bits_per_symbol=1, spreading=1):
+        data = np.ascontiguousarray(data, np.uint8)
+        cfg = capi.McdpskConfig(carriers, bits_per_symbol, spreading, 0)
+        out = np.zeros(600000, np.float32)
+        n = self.lib.ria_gpu_mcdpsk_modulate_host(self.h, C.byref(cfg), data.ctypes.data, len(data), out.ctypes.data, len(out))
+        if n < 0:
+            raise capi.RiaError("mcdpsk_modulate failed")
+        return out[:n].copy()
+
+    def chase_combine(self, acc, count, soft, decoded=None):
+        """ChaseCache::store arithmetic in place on acc [n,648] / count [n] (int32); returns stored flags."""
+        n = acc.shape[0]
+        stored = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_chase_combine_batch(self.h, _ptr(acc), _ptr(count), _ptr(decoded), _ptr(soft), n,
+                                                         _ptr(stored), _stream_ptr()))
+        return stored
+
     def debug_math(self, op, a, b=None):
         out = torch.empty_like(a)
         self._check(self.lib.ria_gpu_debug_math(self.h, op, _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream_ptr()))

@@ -146,3 +146,36 @@ def test_chirp_sync_oracle_matches_reference_golden(oracle, golden):
     for x, r in _chirp_cases(golden, oracle.chirp_generate()):
         out = oracle.chirp_detect(x, 0.15)
         assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (len(x), out, r)
+
+
+def test_mcdpsk_oracle_matches_reference_golden(oracle, golden):
+    """MultiCarrierDPSK modulator (by checksum) and demodulator chain incl. Hilbert CFO correction, spreading
+    2x/4x, DBPSK reliability weights and trailing-silence trimming: LLRs and fading indices bit for bit."""
+    import zlib
+    g = golden("mcdpsk")
+    for i, c in enumerate(g["cases"]):
+        nc, bps, sp = int(c[0]), int(c[1]), int(c[2])
+        tx = oracle.mcdpsk_modulate(nc, bps, sp, g[f"data_{i}"])
+        assert zlib.crc32(tx.tobytes()) == int(g[f"tx_crc_{i}"][0])
+        llr, aux = oracle.mcdpsk_demod(nc, bps, sp, g[f"rx_{i}"], float(c[4]), float(c[5]))
+        assert np.array_equal(llr.view(np.uint32), g[f"llr_{i}"].view(np.uint32)), i
+        assert np.array_equal(aux.view(np.uint32), g[f"aux_{i}"].view(np.uint32)), i
+
+
+def test_chase_combine_oracle_arithmetic(oracle):
+    """ChaseCache::store arithmetic (test_chase_cache-style): first reception copies, later ones add,
+    at most 4 combines, decoded slots untouched."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    acc = np.zeros(648, np.float32)
+    cnt = C.c_int(0)
+    total = np.zeros(648, np.float32)
+    for t in range(6):
+        soft = rng.normal(0, 3, 648).astype(np.float32)
+        ok = oracle.lib.ro_chase_store(acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt), 0, soft.ctypes.data_as(C.POINTER(C.c_float)))
+        if t < 4:
+            total = soft.copy() if t == 0 else total + soft
+            assert ok == 1 and cnt.value == t + 1
+        else:
+            assert ok == 0 and cnt.value == 4
+        assert np.array_equal(acc.view(np.uint32), total.view(np.uint32))
