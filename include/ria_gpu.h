@@ -225,6 +225,22 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
  * returns the sample count or -needed. */
 int ria_gpu_chirp_preamble(ria_gpu_handle h, float* out_host, int max_n);
 
+/* ---- acquisition: LTS light sync (OFDMChirpWaveform::detectDataSync, ofdm_chirp_waveform.cpp:207-384) -------
+ * Training-only preamble of connected-mode DATA frames: energy gate, Hilbert-65 analytic signal, one-symbol
+ * autocorrelation (coarse step 8, early exit above 0.95, +-4 refinement), burst-interleave marker.
+ * Replaces detectDataSync(samples, result, known_cfo_hz, threshold) for n_buffers buffers; every field of
+ * SyncResult it sets is bit-identical (start_sample = first sample of the first LTS symbol). */
+typedef struct ria_lts_result {
+    int32_t detected;
+    int32_t start_sample;
+    float correlation;
+    float cfo_hz;               /* = known_cfo_hz (SyncResult::cfo_hz) */
+    int32_t burst_interleaved;  /* wasBurstInterleaved() */
+    int32_t reserved[3];
+} ria_lts_result;               /* 32 bytes */
+int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                           const float* known_cfo_dev, float threshold, ria_lts_result* out_dev, void* stream);
+
 /* ---- MC-DPSK demodulator (src/psk/multi_carrier_dpsk.hpp) and HARQ chase combine (src/fec/chase_cache.cpp)
  * ria_gpu_mcdpsk_demod_batch replaces MultiCarrierDPSKDemodulator as MCDPSKWaveform::process drives it after
  * an external chirp detection (setChirpDetected + process, multi_carrier_dpsk.hpp:797-896): each frame is

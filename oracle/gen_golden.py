@@ -77,6 +77,31 @@ def mcdpsk_fixture(R):
     return rec
 
 
+def lts_buffers(O, n_cases, seed):
+    """Connected-mode frames (2 LTS + data) behind silence / inside a burst, noise, CFO, negated first LTS."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(n_cases):
+        s, info, coded = O.tx_frame(po.QAM16, po.R1_2, rng.integers(0, 256, 141, dtype=np.uint8), t)
+        s = s * np.float32(0.5 / np.abs(s).max())
+        lead = int(rng.integers(0, 6000)) if t % 4 else 0
+        sigma = [0.002, 0.02, 0.08, 0.2][t % 4]
+        x = np.concatenate([np.zeros(lead, np.float32), s, np.zeros(1500, np.float32)])
+        if t % 5 == 4:
+            x[lead:lead + 1152] *= -1
+        if t % 7 == 6:
+            x = x[lead + 3000:]
+        x = (x + rng.normal(0, sigma, len(x))).astype(np.float32)
+        out.append((x[:21000] if len(x) >= 21000 else np.pad(x, (0, 21000 - len(x))), [0.0, 3.0, -7.5][t % 3]))
+    return out
+
+
+def lts_fixture(R, O):
+    bufs = lts_buffers(O, 12, 606)
+    res = [R.detect_data_sync(x, cfo, 0.5) for x, cfo in bufs]
+    return {"buffers": np.stack([x for x, _ in bufs]), "cfo": np.array([c for _, c in bufs], np.float32), "results": np.stack(res)}
+
+
 def chirp_fixture(R):
     chirp = R.chirp_generate()
     rec = {"preamble_crc": np.array([__import__("zlib").crc32(chirp.tobytes())], np.uint32), "cases": np.array(CHIRP_CASES, np.float32)}
@@ -96,6 +121,7 @@ def main():
         return 2
     os.makedirs(OUT, exist_ok=True)
     R = po.Ref()
+    O = po.Oracle()
     rng = np.random.default_rng(20261004)
 
     # ---- frames
@@ -189,6 +215,7 @@ def main():
     rec = chirp_fixture(R)
     np.savez_compressed(os.path.join(OUT, "chirp_sync.npz"), **rec)
     np.savez_compressed(os.path.join(OUT, "mcdpsk.npz"), **mcdpsk_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "lts_sync.npz"), **lts_fixture(R, O))
     print("done ->", OUT)
     return 0
 

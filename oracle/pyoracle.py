@@ -81,6 +81,7 @@ class Oracle:
         L.ro_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
         L.ro_chirp_generate.argtypes = [_f, C.c_int]
         L.ro_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
+        L.ro_detect_data_sync.argtypes = [_f, C.c_int, C.c_float, C.c_float, _f]
         L.ro_mcdpsk_modulate.argtypes = [C.c_int, C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
         L.ro_mcdpsk_demod.argtypes = [C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _f, C.c_int, _f]
         self._geoms = {}
@@ -102,6 +103,13 @@ class Oracle:
         out = np.zeros(60000, np.float32)
         n = self.lib.ro_chirp_generate(fp(out), len(out))
         return out[:n].copy()
+
+    def detect_data_sync(self, samples, known_cfo=0.0, threshold=0.5):
+        """-> float32[4] {detected, start_sample, correlation, burst_interleaved}"""
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(4, np.float32)
+        self.lib.ro_detect_data_sync(fp(x), len(x), known_cfo, threshold, fp(out))
+        return out
 
     def mcdpsk_modulate(self, nc, bps, spreading, data):
         data = np.ascontiguousarray(data, np.uint8)
@@ -259,6 +267,13 @@ class Ref:
         out = np.zeros(6, np.float32)
         self.lib.ref_chirp_detect(fp(x), len(x), threshold, fp(out))
         return out
+
+    def detect_data_sync(self, samples, known_cfo=0.0, threshold=0.5, mod=QAM16, rate=R1_2):
+        """-> float32[4] {detected, start_sample, correlation, burst_interleaved}"""
+        x = np.ascontiguousarray(samples, np.float32)
+        start, burst, corr = C.c_int(0), C.c_int(0), C.c_float(0)
+        ok = self.lib.ref_detect_data_sync(mod, rate, fp(x), len(x), known_cfo, threshold, C.byref(start), C.byref(corr), C.byref(burst))
+        return np.array([ok, start.value if ok else 0, corr.value, burst.value if ok else 0], np.float32)
 
     def mcdpsk_modulate(self, nc, bps, spreading, data):
         data = np.ascontiguousarray(data, np.uint8)

@@ -114,6 +114,8 @@ int ro_chirp_detect(const float* s, int n, float threshold, float* out6);
 int ro_mcdpsk_modulate(int nc, int bps, int spreading, const uint8_t* data, int n_bytes, float* out, int max_n);
 int ro_mcdpsk_demod(int nc, int bps, int spreading, const float* samples, int n, float cfo_hz, float phase0,
                     float* llr_out, int max_llr, float* aux4);
+/* OFDMChirpWaveform::detectDataSync (LTS light sync); out4 = {detected, start_sample, correlation, burst_interleaved} */
+int ro_detect_data_sync(const float* x, int n, float known_cfo_hz, float threshold, float* out4);
 /* fec::ChaseCache::store arithmetic for one codeword slot (src/fec/chase_cache.cpp:27-88) */
 int ro_chase_store(float* existing, int* combine_count, int decoded, const float* soft);
 

@@ -774,3 +774,99 @@ int ro_chase_store(float* existing, int* combine_count, int decoded, const float
     (*combine_count)++;
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------------ LTS light sync
+ * OFDMChirpWaveform::detectDataSync (src/waveform/ofdm_chirp_waveform.cpp:207-384): energy gate, Hilbert-65
+ * analytic signal (src/dsp/filters.cpp:266-317), one-symbol-delay autocorrelation on a step-8 grid with an
+ * early exit above 0.95, +-4 refinement, burst-interleave marker from the sign of the CFO-compensated peak.
+ * out4 = {detected, start_sample, correlation, burst_interleaved}
+ */
+int ro_detect_data_sync(const float* x, int n, float known_cfo_hz, float threshold, float* out4) {
+    const int L = RO_SYM; /* 1152 */
+    out4[0] = 0.f; out4[1] = 0.f; out4[2] = 0.f; out4[3] = 0.f;
+    const int search_window = L * 4;
+    if (n < L * 3) return 0;
+    float noise_floor = 0.0f;
+    int noise_samples = n / 4 < 4800 ? n / 4 : 4800;
+    for (int i = 0; i < noise_samples; ++i) noise_floor += x[i] * x[i];
+    noise_floor = sqrtf(noise_floor / noise_samples);
+    float energy_threshold = noise_floor * 3.0f + 0.01f;
+    int signal_start = 0;
+    int signal_in_noise = noise_floor < 0.05f;
+    if (signal_in_noise) {
+        for (int i = 0; i < n - L * 2; ++i) {
+            float energy = 0.0f;
+            for (int j = 0; j < 64; ++j) if (i + j < n) energy += x[i + j] * x[i + j];
+            energy = sqrtf(energy / 64);
+            if (energy > energy_threshold) { signal_start = i; break; }
+        }
+    }
+    enum { TAPS = 65, M = 32 };
+    float coeff[TAPS];
+    for (int k = 0; k < TAPS; ++k) {
+        int kk = k - M;
+        if (kk == 0) coeff[k] = 0;
+        else if (kk % 2 != 0) coeff[k] = (float)(2.0f / (M_PI * kk));
+        else coeff[k] = 0;
+        float w = (float)(2.0f * M_PI * k / (TAPS - 1));
+        coeff[k] *= 0.42f - 0.5f * cosf(w) + 0.08f * cosf(2.0f * w);
+    }
+    float* ar = (float*)malloc(sizeof(float) * (size_t)n);
+    float* ai = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float q = 0;
+        for (int k = 0; k < TAPS; ++k) q += coeff[k] * ((i - k >= 0) ? x[i - k] : 0.0f);
+        ar[i] = (i - M >= 0) ? x[i - M] : 0.0f;
+        ai[i] = q;
+    }
+    float best_corr = 0.0f, bpr = 0.0f, bpi = 0.0f;
+    int best_offset = 0;
+    int max_connected = search_window > L * 8 ? search_window : L * 8;
+    int actual = signal_in_noise ? search_window : max_connected;
+    int search_end = signal_start + actual < n - L * 2 ? signal_start + actual : n - L * 2;
+#define RO_LTS_CORR(offset, corr_out, pr_out, pi_out)                                              \
+    do {                                                                                           \
+        float pr_ = 0.0f, pi_ = 0.0f, e1_ = 0.0f, e2_ = 0.0f;                                      \
+        for (int nn = 0; nn < L; ++nn) {                                                           \
+            int i1 = (offset) + nn, i2 = (offset) + nn + L;                                        \
+            if (i2 >= n) break;                                                                    \
+            /* conj(s1) * s2 */                                                                    \
+            float a = ar[i1], b = -ai[i1], c = ar[i2], d = ai[i2];                                 \
+            pr_ += a * c - b * d;                                                                  \
+            pi_ += a * d + b * c;                                                                  \
+            e1_ += ar[i1] * ar[i1] + ai[i1] * ai[i1];                                              \
+            e2_ += c * c + d * d;                                                                  \
+        }                                                                                          \
+        float den_ = sqrtf(e1_ * e2_) + 1e-10f;                                                    \
+        corr_out = hypotf(pr_, pi_) / den_; pr_out = pr_; pi_out = pi_;                            \
+    } while (0)
+    for (int offset = signal_start; offset < search_end; offset += 8) {
+        float corr, pr, pi;
+        RO_LTS_CORR(offset, corr, pr, pi);
+        if (corr > best_corr) { best_corr = corr; best_offset = offset; bpr = pr; bpi = pi; }
+        if (corr > 0.95f) break;
+    }
+    if (best_corr > threshold) {
+        int rs = signal_start > best_offset - 4 ? signal_start : best_offset - 4;
+        int re = search_end < best_offset + 5 ? search_end : best_offset + 5;
+        int center = best_offset;
+        for (int offset = rs; offset < re; ++offset) {
+            if (offset == center) continue;
+            float corr, pr, pi;
+            RO_LTS_CORR(offset, corr, pr, pi);
+            if (corr > best_corr) { best_corr = corr; best_offset = offset; bpr = pr; bpi = pi; }
+        }
+    }
+    free(ar); free(ai);
+    out4[2] = best_corr;
+    if (best_corr > threshold) {
+        out4[0] = 1.f;
+        out4[1] = (float)best_offset;
+        float cfo_phase = (float)(2.0f * M_PI * known_cfo_hz * L / 48000.0f);
+        float cr = cosf(-cfo_phase), ci = sinf(-cfo_phase);
+        float mr = bpr * cr - bpi * ci;
+        out4[3] = (mr < 0.0f) ? 1.f : 0.f;
+        return 1;
+    }
+    return 0;
+}

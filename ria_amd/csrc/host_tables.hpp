@@ -632,8 +632,10 @@ inline std::vector<float> build_mcdpsk_mixer(int nc) {
     }
     return m;
 }
-inline std::vector<float> build_hilbert127() {   // filters.cpp:266-291
-    const int taps = 127, M = 63;
+inline std::vector<float> build_hilbert(int taps);
+inline std::vector<float> build_hilbert127() { return build_hilbert(127); }
+inline std::vector<float> build_hilbert(int taps) {   // HilbertTransform ctor, filters.cpp:266-291 (taps odd)
+    const int M = (taps - 1) / 2;
     std::vector<float> c(taps);
     for (int n = 0; n < taps; ++n) {
         const int k = n - M;

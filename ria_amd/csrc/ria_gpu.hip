@@ -46,7 +46,7 @@ struct ria_gpu {
     void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
     int ch_chunk = 0;
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
-    std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
+    std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
     void* d_demod_const = nullptr;
     void* d_tx_const = nullptr;
@@ -360,6 +360,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : h->d_mc_mixer) if (kv.second) (void)hipFree(kv.second);
     if (h->d_mc_hilbert) (void)hipFree(h->d_mc_hilbert);
+    if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
@@ -874,6 +875,26 @@ int ria_gpu_chirp_preamble(ria_gpu_handle h, float* out_host, int max_n) {
     if (static_cast<int>(p.size()) > max_n) return -static_cast<int>(p.size());
     std::memcpy(out_host, p.data(), p.size() * sizeof(float));
     return static_cast<int>(p.size());
+}
+
+int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                           const float* known_cfo_dev, float threshold, ria_lts_result* out_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_buffers == 0) return RIA_OK;
+    if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || stride < buf_len)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_lts_batch: bad arguments");
+    if (!h->d_hilbert65) { std::vector<float> hc = build_hilbert(65); HIP_TRY(h, upload(&h->d_hilbert65, hc)); }
+    static std::atomic<int> opted{0};
+    if (!opted.load()) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lts_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lts_lds_bytes()));
+        opted.store(1);
+    }
+    LtsArgs A{};
+    A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.n_buffers = n_buffers; A.known_cfo = known_cfo_dev;
+    A.threshold = threshold; A.hilbert = static_cast<const float*>(h->d_hilbert65); A.out = out_dev;
+    hipLaunchKernelGGL(lts_sync_kernel, dim3(n_buffers), dim3(256), lts_lds_bytes(), static_cast<hipStream_t>(stream), A);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
 }
 
 static bool mcdpsk_config_ok(const ria_mcdpsk_config* c) {

@@ -495,4 +495,153 @@ __global__ void chirp_finish_kernel(ChirpArgs A) {
     A.out[A.first + b] = o;
 }
 
+// =====================================================================================================
+// LTS light sync: OFDMChirpWaveform::detectDataSync (src/waveform/ofdm_chirp_waveform.cpp:207-384), bit-exact.
+// One workgroup per capture buffer: energy gate (first 64-sample window above 3x the noise floor),
+// Hilbert-65 analytic signal of the search span into LDS, one LANE per candidate offset for the
+// one-symbol-delay autocorrelation (a 1152-term left-to-right complex sum), then the reference's sequential
+// rules replayed over the per-offset results: stop at the first correlation above 0.95, first maximum up
+// to there, +-4 refinement, burst-interleave marker from the sign of the CFO-compensated peak.
+constexpr int kLtsSym = 1152, kLtsTaps = 65, kLtsMaxSpan = 10 * kLtsSym, kLtsMaxOffsets = kLtsSym + 8;
+
+struct LtsArgs {
+    const float* samples; long long stride; int buf_len; int n_buffers;
+    const float* known_cfo; float threshold;
+    const float* hilbert;       // [65]
+    ria_lts_result* out;
+};
+
+__host__ __device__ inline int lts_lds_bytes() { return kLtsMaxSpan * 8 + kLtsMaxOffsets * 12 + 64; }
+
+struct LtsCorr { float corr, pr, pi; };
+__device__ inline LtsCorr lts_corr_at(const float2* __restrict__ an, int rel, int offset, int n) {
+    float pr = 0.0f, pi = 0.0f, e1 = 0.0f, e2 = 0.0f;
+    const float2* p1 = an + rel;
+    const float2* p2 = p1 + kLtsSym;
+    for (int k = 0; k < kLtsSym; ++k) {
+        if (offset + k + kLtsSym >= n) break;
+        const float2 s1 = p1[k], s2 = p2[k];
+        const float a = s1.x, b = -s1.y, c = s2.x, d = s2.y;     // conj(s1) * s2
+        pr += a * c - b * d;
+        pi += a * d + b * c;
+        e1 += s1.x * s1.x + s1.y * s1.y;
+        e2 += c * c + d * d;
+    }
+    const float den = fsqrt(e1 * e2) + 1e-10f;
+    return {fdiv(hypotf_glibc(pr, pi), den), pr, pi};
+}
+
+__global__ __launch_bounds__(256) void lts_sync_kernel(LtsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* an = reinterpret_cast<float2*>(smem);                         // analytic signal of [base, base + span)
+    float* ccorr = reinterpret_cast<float*>(an + kLtsMaxSpan);             // per coarse offset
+    float* cpr = ccorr + kLtsMaxOffsets;
+    float* cpi = cpr + kLtsMaxOffsets;
+    __shared__ float sh_noise; __shared__ int sh_start;
+    const int tid = threadIdx.x, n = A.buf_len, L = kLtsSym;
+    const float* x = A.samples + static_cast<long long>(blockIdx.x) * A.stride;
+    ria_lts_result* out = A.out + blockIdx.x;
+    const float known = A.known_cfo ? A.known_cfo[blockIdx.x] : 0.0f;
+    if (n < 3 * L) {
+        if (tid == 0) { out->detected = 0; out->start_sample = 0; out->correlation = 0.f; out->cfo_hz = known; out->burst_interleaved = 0; out->reserved[0] = out->reserved[1] = out->reserved[2] = 0; }
+        return;
+    }
+    if (tid == 0) {   // noise floor over the first min(n/4, 4800) samples (:232-237)
+        const int ns = n / 4 < 4800 ? n / 4 : 4800;
+        float acc = 0.0f;
+        for (int i = 0; i < ns; ++i) acc += x[i] * x[i];
+        sh_noise = fsqrt(fdiv(acc, static_cast<float>(ns)));
+        sh_start = 0x7fffffff;
+    }
+    __syncthreads();
+    const float noise_floor = sh_noise;
+    const float energy_threshold = noise_floor * 3.0f + 0.01f;
+    const bool in_noise = noise_floor < 0.05f;
+    int signal_start = 0;
+    if (in_noise) {   // first window of 64 samples whose rms exceeds the threshold (:243-258)
+        const int lim = n - 2 * L;
+        for (int base = 0; base < lim; base += 256) {
+            const int i = base + tid;
+            bool hit = false;
+            if (i < lim) {
+                float e = 0.0f;
+                for (int j = 0; j < 64; ++j) if (i + j < n) e += x[i + j] * x[i + j];
+                hit = fsqrt(fdiv(e, 64.0f)) > energy_threshold;
+            }
+            if (hit) atomicMin(&sh_start, i);
+            __syncthreads();
+            const int cur = sh_start;
+            __syncthreads();
+            if (cur != 0x7fffffff) break;
+        }
+        __syncthreads();
+        signal_start = (sh_start == 0x7fffffff) ? 0 : sh_start;
+    }
+    const int search_window = 4 * L, max_connected = 8 * L;
+    const int actual = in_noise ? search_window : max_connected;
+    const int search_end = (signal_start + actual < n - 2 * L) ? signal_start + actual : n - 2 * L;
+    // analytic signal (HilbertTransform(65).process, filters.cpp:293-317) of the span the search touches
+    const int base = signal_start;
+    int span = search_end + 2 * L - base;
+    if (base + span > n) span = n - base;
+    if (span < 0) span = 0;
+    for (int r = tid; r < span; r += 256) {
+        const int i = base + r;
+        float q = 0.0f;
+        for (int k = 0; k < kLtsTaps; ++k) q += A.hilbert[k] * ((i - k >= 0) ? x[i - k] : 0.0f);
+        an[r] = make_float2((i - 32 >= 0) ? x[i - 32] : 0.0f, q);
+    }
+    __syncthreads();
+    // coarse grid, step 8 (:279-316)
+    const int K = (search_end > signal_start) ? (search_end - signal_start + 7) / 8 : 0;
+    for (int k = tid; k < K; k += 256) {
+        const LtsCorr c = lts_corr_at(an, 8 * k, signal_start + 8 * k, n);
+        ccorr[k] = c.corr; cpr[k] = c.pr; cpi[k] = c.pi;
+    }
+    __syncthreads();
+    __shared__ float sh_best; __shared__ int sh_off; __shared__ float sh_pr, sh_pi;
+    if (tid == 0) {
+        float best = 0.0f, bpr = 0.0f, bpi = 0.0f; int boff = 0;
+        for (int k = 0; k < K; ++k) {
+            if (ccorr[k] > best) { best = ccorr[k]; boff = signal_start + 8 * k; bpr = cpr[k]; bpi = cpi[k]; }
+            if (ccorr[k] > 0.95f) break;
+        }
+        sh_best = best; sh_off = boff; sh_pr = bpr; sh_pi = bpi;
+    }
+    __syncthreads();
+    float best = sh_best; int boff = sh_off;
+    // +-4 refinement (:322-353)
+    if (best > A.threshold) {
+        const int rs = (signal_start > boff - 4) ? signal_start : boff - 4;
+        const int re = (search_end < boff + 5) ? search_end : boff + 5;
+        if (tid < 9) {
+            const int off = rs + tid;
+            if (off < re && off != boff) {
+                const LtsCorr c = lts_corr_at(an, off - base, off, n);
+                ccorr[tid] = c.corr; cpr[tid] = c.pr; cpi[tid] = c.pi;
+            } else ccorr[tid] = -1.0f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float b = best, bpr = sh_pr, bpi = sh_pi; int bo = boff;
+            for (int q = 0; q < 9; ++q) if (ccorr[q] > b) { b = ccorr[q]; bo = rs + q; bpr = cpr[q]; bpi = cpi[q]; }
+            sh_best = b; sh_off = bo; sh_pr = bpr; sh_pi = bpi;
+        }
+        __syncthreads();
+        best = sh_best; boff = sh_off;
+    }
+    if (tid == 0) {
+        ria_lts_result o;
+        o.detected = 0; o.start_sample = 0; o.correlation = best; o.cfo_hz = known; o.burst_interleaved = 0;
+        o.reserved[0] = o.reserved[1] = o.reserved[2] = 0;
+        if (best > A.threshold) {
+            o.detected = 1; o.start_sample = boff;
+            const float cfo_phase = static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(known) * static_cast<double>(L) / static_cast<double>(48000.0f));
+            const float cr = cosf_glibc(-cfo_phase), ci = sinf_glibc(-cfo_phase);
+            o.burst_interleaved = (sh_pr * cr - sh_pi * ci < 0.0f) ? 1 : 0;
+        }
+        *out = o;
+    }
+}
+
 }  // namespace ria

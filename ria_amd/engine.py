@@ -192,6 +192,18 @@ class RxEngine:
             raise capi.RiaError("chirp_preamble: buffer too small")
         return out[:n].copy()
 
+    LTS_RESULT = np.dtype([("detected", "<i4"), ("start_sample", "<i4"), ("correlation", "<f4"), ("cfo_hz", "<f4"),
+                           ("burst_interleaved", "<i4"), ("reserved", "<i4", 3)])
+
+    def sync_lts(self, buffers, known_cfo=None, threshold=0.5):
+        """OFDMChirpWaveform::detectDataSync over a batch: buffers float32 [n, buf_len] on the device."""
+        n, buf_len = buffers.shape
+        assert buffers.dtype == torch.float32 and buffers.is_contiguous()
+        out = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_sync_lts_batch(self.h, _ptr(buffers), buf_len, buf_len, n, _ptr(known_cfo), float(threshold),
+                                                    _ptr(out), _stream_ptr()))
+        return self._status_array(out, self.LTS_RESULT)
+
     MCDPSK_STATUS = np.dtype([("cfo_hz", "<f4"), ("fading_index", "<f4"), ("freq_fading_index", "<f4"),
                               ("temporal_fading_index", "<f4"), ("training_cfo_residual", "<f4"), ("n_llr", "<i4"),
                               ("valid_symbols", "<i4"), ("reserved", "<i4")])

@@ -398,6 +398,29 @@ def test_chase_combine_matches_reference_arithmetic():
     assert np.array_equal(cnt.cpu().numpy(), exp_cnt)
 
 
+def _lts_fields(r):
+    return np.stack([r["detected"].astype(np.float32), r["start_sample"].astype(np.float32), r["correlation"],
+                     r["burst_interleaved"].astype(np.float32)], axis=1)
+
+
+def test_lts_sync_matches_reference_golden_and_oracle(oracle, golden):
+    """ria_gpu_sync_lts_batch vs SyncResult recorded from the reference, then a larger oracle-checked batch."""
+    import gen_golden
+    e = engine("QAM16", "R1_2")
+    g = golden("lts_sync")
+    out = _lts_fields(e.sync_lts(dev(g["buffers"]), dev(g["cfo"]), 0.5))
+    assert np.array_equal(out.view(np.uint32), g["results"].view(np.uint32)), (out, g["results"])
+    bufs = gen_golden.lts_buffers(oracle, 60, 1234)
+    X = np.stack([x for x, _ in bufs]); cfo = np.array([c for _, c in bufs], np.float32)
+    out = _lts_fields(e.sync_lts(dev(X), dev(cfo), 0.5))
+    n_det = 0
+    for i in range(len(bufs)):
+        exp = oracle.detect_data_sync(X[i], float(cfo[i]), 0.5)
+        assert np.array_equal(out[i].view(np.uint32), exp.view(np.uint32)), (i, out[i], exp)
+        n_det += int(exp[0])
+    assert n_det >= 30
+
+
 def test_loopback_round_trip_full_size():
     """Size-independent property at bench scale: make_frames -> tx -> AWGN 20 dB -> rx returns the
     transmitted bytes for (nearly) every frame, and frame_valid agrees with byte equality."""

@@ -179,3 +179,11 @@ def test_chase_combine_oracle_arithmetic(oracle):
         else:
             assert ok == 0 and cnt.value == 4
         assert np.array_equal(acc.view(np.uint32), total.view(np.uint32))
+
+
+def test_lts_sync_oracle_matches_reference_golden(oracle, golden):
+    """OFDMChirpWaveform::detectDataSync: detected / start_sample / correlation / burst marker, bit for bit."""
+    g = golden("lts_sync")
+    for x, cfo, r in zip(g["buffers"], g["cfo"], g["results"]):
+        out = oracle.detect_data_sync(x, float(cfo), 0.5)
+        assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (out, r)
