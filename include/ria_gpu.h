@@ -275,6 +275,21 @@ int ria_gpu_mcdpsk_modulate_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg,
 int ria_gpu_chase_combine_batch(ria_gpu_handle h, float* acc_dev, int32_t* count_dev, const uint8_t* decoded_dev,
                                 const float* soft_dev, int n_cw, uint8_t* stored_out_dev, void* stream);
 
+/* ---- link adaptation ladder (host scalars; src/protocol/waveform_selection.hpp:49-104,112-222,250-314) -----
+ * waveform: protocol::WaveformMode value (4 MC_DPSK, 5 OFDM_CHIRP); spreading 1/2/4. */
+typedef struct ria_link_recommendation {
+    int32_t waveform;
+    int32_t modulation;
+    int32_t code_rate;
+    int32_t spreading;
+    int32_t num_carriers;
+    float estimated_throughput_bps;   /* 0 from ria_link_data_mode for OFDM (the reference does not report one) */
+} ria_link_recommendation;
+void ria_link_recommend(float snr_db, float fading_index, ria_link_recommendation* out);          /* recommendWaveformAndRate */
+void ria_link_data_mode(float snr_db, int waveform, float fading_index, ria_link_recommendation* out);   /* recommendDataMode */
+int ria_link_ofdm_code_rate(float snr_db, float fading_index);                                     /* selectOFDMCodeRate */
+int ria_link_cap_initial_rate(float snr_db, float fading_index, int candidate_rate);               /* capInitialOFDMRate */
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

@@ -41,6 +41,7 @@
 #include "fec/ldpc_codec.hpp"
 #include "protocol/frame_v2.hpp"
 #include "sim/hf_channel.hpp"
+#include "protocol/waveform_selection.hpp"
 #include "sync/chirp_sync.hpp"
 #include "sync/zc_sync.hpp"
 #include "psk/multi_carrier_dpsk.hpp"
@@ -355,6 +356,26 @@ int ref_mcdpsk_demod(int carriers, int bps, int spreading, const float* samples,
     std::memcpy(llr_out, sb.data(), sb.size() * sizeof(float));
     aux4[0] = cfo; aux4[1] = fading; aux4[2] = ffi; aux4[3] = tfi;
     return m;
+}
+
+// protocol::recommendWaveformAndRate / recommendDataMode / selectOFDMCodeRate / capInitialOFDMRate
+// (src/protocol/waveform_selection.hpp)
+void ref_link_recommend(float snr, float fading, float* out6) {
+    auto r = protocol::recommendWaveformAndRate(snr, fading);
+    out6[0] = static_cast<float>(static_cast<int>(r.waveform)); out6[1] = static_cast<float>(static_cast<int>(r.modulation));
+    out6[2] = static_cast<float>(static_cast<int>(r.rate));
+    out6[3] = r.spreading == SpreadingMode::TIME_4X ? 4.f : r.spreading == SpreadingMode::TIME_2X ? 2.f : 1.f;
+    out6[4] = static_cast<float>(r.num_carriers); out6[5] = r.estimated_throughput_bps;
+}
+void ref_link_data_mode(float snr, int waveform, float fading, float* out4) {
+    Modulation mod = Modulation::DQPSK; CodeRate rate = CodeRate::R1_4; int nc = 10; SpreadingMode sp = SpreadingMode::NONE;
+    protocol::recommendDataMode(snr, static_cast<protocol::WaveformMode>(waveform), mod, rate, fading, &nc, &sp);
+    out4[0] = static_cast<float>(static_cast<int>(mod)); out4[1] = static_cast<float>(static_cast<int>(rate));
+    out4[2] = sp == SpreadingMode::TIME_4X ? 4.f : sp == SpreadingMode::TIME_2X ? 2.f : 1.f; out4[3] = static_cast<float>(nc);
+}
+int ref_link_ofdm_code_rate(float snr, float fading) { return static_cast<int>(protocol::selectOFDMCodeRate(snr, fading)); }
+int ref_link_cap_initial_rate(float snr, float fading, int cand) {
+    return static_cast<int>(protocol::capInitialOFDMRate(snr, fading, static_cast<CodeRate>(cand)));
 }
 
 }  // extern "C"

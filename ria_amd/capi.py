@@ -18,6 +18,7 @@ EXPORTS = [
     "ria_gpu_rx_batch", "ria_gpu_rx_frames_host", "ria_gpu_decode_frames_host", "ria_gpu_tx_batch", "ria_gpu_make_frames",
     "ria_gpu_channel_batch", "ria_gpu_debug_math", "ria_gpu_sync_zc_batch", "ria_gpu_zc_preamble", "ria_gpu_sync_chirp_batch", "ria_gpu_chirp_preamble", "ria_gpu_mcdpsk_demod_batch",
     "ria_gpu_mcdpsk_modulate_host", "ria_gpu_chase_combine_batch", "ria_gpu_sync_lts_batch",
+    "ria_link_recommend", "ria_link_data_mode", "ria_link_ofdm_code_rate", "ria_link_cap_initial_rate",
 ]
 
 
@@ -25,6 +26,11 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "device", "modulation", "code_rate", "fft_size",
                                           "num_carriers", "cyclic_prefix", "sample_rate", "center_freq",
                                           "max_batch")] + [("reserved", C.c_int32 * 6)]
+
+
+class LinkRecommendation(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("waveform", "modulation", "code_rate", "spreading", "num_carriers")] + \
+               [("estimated_throughput_bps", C.c_float)]
 
 
 class McdpskConfig(C.Structure):
@@ -102,8 +108,14 @@ def load(build_if_needed=True):
     L.ria_gpu_mcdpsk_modulate_host.argtypes = [vp, vp, vp, i32, vp, i32]
     L.ria_gpu_chase_combine_batch.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.ria_gpu_sync_lts_batch.argtypes = [vp, vp, C.c_int64, i32, i32, vp, f32, vp, vp]
+    L.ria_link_recommend.argtypes = [f32, f32, C.POINTER(LinkRecommendation)]
+    L.ria_link_recommend.restype = None
+    L.ria_link_data_mode.argtypes = [f32, i32, f32, C.POINTER(LinkRecommendation)]
+    L.ria_link_data_mode.restype = None
+    L.ria_link_ofdm_code_rate.argtypes = [f32, f32]
+    L.ria_link_cap_initial_rate.argtypes = [f32, f32, i32]
     for name in EXPORTS:
-        if name not in ("ria_gpu_default_config", "ria_gpu_destroy", "ria_gpu_last_error"):
+        if name not in ("ria_gpu_default_config", "ria_gpu_destroy", "ria_gpu_last_error", "ria_link_recommend", "ria_link_data_mode"):
             getattr(L, name).restype = i32
     _lib = L
     return L

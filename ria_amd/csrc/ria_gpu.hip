@@ -18,6 +18,7 @@
 
 #include "../../include/ria_gpu.h"
 #include "host_tables.hpp"
+#include "../host/link_adaptation.hpp"
 #include "frame_recovery.hpp"
 #include "ldpc_kernels.hip.h"
 #include "ldpc_fast.hip.h"
@@ -971,6 +972,15 @@ int ria_gpu_chase_combine_batch(ria_gpu_handle h, float* acc_dev, int32_t* count
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }
+
+void ria_link_recommend(float snr_db, float fading_index, ria_link_recommendation* out) { if (out) *out = recommend_waveform_and_rate(snr_db, fading_index); }
+void ria_link_data_mode(float snr_db, int waveform, float fading_index, ria_link_recommendation* out) {
+    if (!out) return;
+    *out = recommend_data_mode(snr_db, waveform, fading_index);
+    if (waveform != kWaveMcDpsk) out->estimated_throughput_bps = 0.0f;
+}
+int ria_link_ofdm_code_rate(float snr_db, float fading_index) { return select_ofdm_code_rate(snr_db, fading_index); }
+int ria_link_cap_initial_rate(float snr_db, float fading_index, int candidate_rate) { return cap_initial_ofdm_rate(snr_db, fading_index, candidate_rate); }
 
 int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n, float* out_dev,
                        void* stream) {

@@ -11,7 +11,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     from ria_amd import capi
     L = capi.load()
     header = open(os.path.join(ROOT, "include", "ria_gpu.h")).read()
-    declared = set(re.findall(r"\b(ria_gpu_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(ria_(?:gpu|link)_[a-z0-9_]+)\s*\(", header))
     declared -= {"ria_gpu_config", "ria_gpu_geometry", "ria_gpu_handle"}
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
@@ -26,6 +26,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.FrameMeta) == 16
     assert C.sizeof(capi.FrameStatus) == 32
     assert C.sizeof(capi.DecodeStatus) == 20
+    assert C.sizeof(capi.McdpskConfig) == 16
+    assert C.sizeof(capi.LinkRecommendation) == 24
 
 
 def test_create_rejects_bad_config_without_a_gpu():
@@ -49,3 +51,27 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(d, f), errors="ignore").read()
                 assert "pyoracle" not in src and "ria_oracle" not in src and "libria_ref" not in src, f
+
+
+def test_link_adaptation_ladder_matches_reference_grid(golden):
+    """recommendWaveformAndRate / recommendDataMode / selectOFDMCodeRate / capInitialOFDMRate
+    (waveform_selection.hpp) over a dense (snr, fading) grid recorded from the reference; host scalars,
+    so this runs without a GPU through the C ABI."""
+    import ctypes as C
+    import numpy as np
+    from ria_amd import capi
+    L = capi.load()
+    g = golden("link_adaptation")
+    o = capi.LinkRecommendation()
+    for i, s in enumerate(g["snr"]):
+        for j, f in enumerate(g["fading"]):
+            L.ria_link_recommend(float(s), float(f), C.byref(o))
+            got = [o.waveform, o.modulation, o.code_rate, o.spreading, o.num_carriers, o.estimated_throughput_bps]
+            assert np.array_equal(np.array(got, np.float32), g["recommend"][i, j]), (s, f, got, g["recommend"][i, j])
+            for w, wave in enumerate((4, 5)):
+                L.ria_link_data_mode(float(s), wave, float(f), C.byref(o))
+                got = [o.modulation, o.code_rate, o.spreading, o.num_carriers]
+                assert np.array_equal(np.array(got, np.float32), g["data_mode"][i, j, w]), (s, f, wave, got)
+            assert L.ria_link_ofdm_code_rate(float(s), float(f)) == g["rate"][i, j]
+            assert L.ria_link_cap_initial_rate(float(s), float(f), 4) == g["cap"][i, j, 0]
+            assert L.ria_link_cap_initial_rate(float(s), float(f), 3) == g["cap"][i, j, 1]
