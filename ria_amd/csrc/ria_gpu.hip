@@ -858,11 +858,11 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
         for (int down = 0; down < 2; ++down) {
             A.down = down;
             hipLaunchKernelGGL(chirp_window_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
-            hipLaunchKernelGGL(chirp_cumsum_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(chirp_cumsum_kernel, dim3(nb), dim3(64), 0, s, A);
             chirp_fft_forward(A, nb, s, true, true);
             chirp_fft_inverse_mag(A, nb, s);
             hipLaunchKernelGGL(chirp_peak_kernel, dim3(nb), dim3(256), 0, s, A);
-            if (down) hipLaunchKernelGGL(chirp_td_kernel, dim3(nb), dim3(64), 0, s, A);
+            if (down) hipLaunchKernelGGL(chirp_td_kernel, dim3(nb), dim3(256), 0, s, A);
         }
         hipLaunchKernelGGL(chirp_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
     }

@@ -247,6 +247,11 @@ struct ChirpArgs {
     int down;                  // stage: 0 up, 1 down
 };
 
+__device__ __forceinline__ void wave_lds_fence() {   // single-wave workgroup: DS ops execute in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ float2 ch_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ void ch_bfly(float2& a, float2& b, float2 w) {  // fft.cpp:113-117
     const float2 t = ch_cmul(w, b);
@@ -287,26 +292,57 @@ __global__ void chirp_window_kernel(ChirpArgs A) {
     s.active = (s.win_len >= 2 * kChLen) ? 1 : 2;
 }
 
-// cumsum_energy[i+1] = cumsum_energy[i] + s[i]^2 (chirp_sync.hpp:668-672): one lane per buffer
+// cumsum_energy[i+1] = cumsum_energy[i] + s[i]^2 (chirp_sync.hpp:668-672).  The running float sum is serial by
+// definition; one wavefront per buffer: all lanes load a tile and square it (coalesced), lane 0 walks the
+// tile through LDS (the dependent adds are the whole cost), all lanes store the tile (coalesced).
 __global__ __launch_bounds__(64) void chirp_cumsum_kernel(ChirpArgs A) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= A.n_buffers) return;
+    __shared__ __attribute__((aligned(16))) float sq[256];
+    __shared__ __attribute__((aligned(16))) float cs[256];
+    const int b = blockIdx.x, lane = threadIdx.x;
     const ChirpBufState s = A.st[b];
     if (s.active != 1) return;
     const float* x = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
     float* cum = A.cum + static_cast<size_t>(b) * (kChFft + 1);
     const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
     float c = 0.0f;
-    cum[0] = 0.0f;
-    int i = 0;
-    for (; i + 8 <= fft_in; i += 8) {
-        float v[8];
+    if (lane == 0) cum[0] = 0.0f;
+    for (int base = 0; base < fft_in; base += 256) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = x[i + q];
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + 64 * q + lane;
+            const float v = (i < fft_in) ? x[i] : 0.0f;
+            sq[64 * q + lane] = v * v;
+        }
+        wave_lds_fence();
+        if (lane == 0) {
+            // register blocks of 32 samples: the loads of a block do not wait for the stores of the previous
+            // one (separate input / output arrays), so only the dependent adds are on the critical path
+            const float4* in = reinterpret_cast<const float4*>(sq);
+            float4* outp = reinterpret_cast<float4*>(cs);
+#pragma unroll 2
+            for (int blk = 0; blk < 8; ++blk) {
+                float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { c = c + v[q] * v[q]; cum[i + q + 1] = c; }
+                for (int q = 0; q < 8; ++q) v[q] = in[8 * blk + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    c = c + v[q].x; v[q].x = c;
+                    c = c + v[q].y; v[q].y = c;
+                    c = c + v[q].z; v[q].z = c;
+                    c = c + v[q].w; v[q].w = c;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) outp[8 * blk + q] = v[q];
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + 64 * q + lane;
+            if (i < fft_in) cum[i + 1] = cs[64 * q + lane];
+        }
+        wave_lds_fence();
     }
-    for (; i < fft_in; ++i) { const float v = x[i]; c = c + v * v; cum[i + 1] = c; }
 }
 
 // One pass of the 131072-point radix-2 DIT FFT: stages S0+1 .. S0+G on 2^G elements per thread.
@@ -423,8 +459,9 @@ __device__ inline float chirp_td_corr(const float* x, int n, int offset, const f
     if (denom < 1e-10f) return 0.0f;
     return fdiv(fsqrt(ci * ci + cq * cq), denom);
 }
-__global__ __launch_bounds__(64) void chirp_td_kernel(ChirpArgs A) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void chirp_td_kernel(ChirpArgs A) {
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sbest; __shared__ int spos;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     ChirpBufState& s = A.st[b];
     if (s.active != 2) return;
     const float* x = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
@@ -432,42 +469,60 @@ __global__ __launch_bounds__(64) void chirp_td_kernel(ChirpArgs A) {
     const float* tsin = A.tmpl + static_cast<size_t>(2 * A.down) * kChLen;
     const float* tcos = tsin + kChLen;
     const float te = A.tmpl_energy[A.down];
+    // block-wide "first maximum" of (value, index) pairs; -1 marks lanes without a candidate
+    auto block_argmax = [&](float v, int idx, float& ov, int& oi) {
+        wave_argmax_first(v, idx);
+        __syncthreads();
+        if (lane == 0) { sv[wv] = v; si[wv] = idx; }
+        __syncthreads();
+        ov = sv[0]; oi = si[0];
+        for (int w = 1; w < 4; ++w) if (sv[w] > ov || (sv[w] == ov && si[w] < oi)) { ov = sv[w]; oi = si[w]; }
+    };
     float best = 0.0f; int best_pos = -1;
     const int n_coarse = (search_len + 47) / 48;
-    for (int base = 0; base < n_coarse; base += 64) {
-        const int k = base + lane;
+    for (int base = 0; base < n_coarse; base += 256) {       // coarse grid, step 48 (:763-773)
+        const int k = base + tid;
         const bool valid = k < n_coarse;
-        float c = chirp_td_corr(x, n, valid ? k * 48 : 0, tsin, tcos, te);
-        float v = valid ? c : -1.0f; int idx = k * 48;
-        wave_argmax_first(v, idx);
+        const float c = chirp_td_corr(x, n, valid ? k * 48 : 0, tsin, tcos, te);
+        float v; int idx;
+        block_argmax(valid ? c : -1.0f, k * 48, v, idx);
         if (v > best) { best = v; best_pos = idx; }
     }
     int pos_out = -1;
     if (!(best_pos < 0 || best < A.threshold * 0.3f)) {
         const int fine_start = best_pos - 48 < 0 ? 0 : best_pos - 48;
         const int fine_end = best_pos + 48 > search_len ? search_len : best_pos + 48;
-        for (int base = fine_start; base <= fine_end; base += 64) {
-            const int p = base + lane;
+        {   // fine search, inclusive range of at most 97 positions (:788-795)
+            const int p = fine_start + tid;
             const bool valid = p <= fine_end;
-            float c = chirp_td_corr(x, n, valid ? p : 0, tsin, tcos, te);
-            float v = valid ? c : -1.0f; int idx = p;
-            wave_argmax_first(v, idx);
+            const float c = (tid < 128) ? chirp_td_corr(x, n, valid ? p : 0, tsin, tcos, te) : 0.0f;
+            float v; int idx;
+            block_argmax(valid ? c : -1.0f, p, v, idx);
             if (v > best) { best = v; best_pos = idx; }
         }
-        if (best_pos > 0 && best_pos < search_len - 1) {
-            const float cc = chirp_td_corr(x, n, best_pos + (lane == 0 ? -1 : 1), tsin, tcos, te);   // lanes 0, 1 matter
-            const float c0 = __shfl(cc, 0), c1 = best, c2 = __shfl(cc, 1);
-            const float denom = 2.0f * (c0 - 2.0f * c1 + c2);
-            if (fabs_(denom) > 1e-10f) {
-                float delta = fdiv(c0 - c2, denom);
-                const float lo = (1.0f < delta) ? 1.0f : delta;
-                delta = (-1.0f < lo) ? lo : -1.0f;
-                best_pos = static_cast<int>(__builtin_roundf(static_cast<float>(best_pos) + delta));
+        if (best_pos > 0 && best_pos < search_len - 1) {     // parabolic interpolation (:798-809)
+            float cc = 0.0f;
+            if (tid < 2) cc = chirp_td_corr(x, n, best_pos + (tid == 0 ? -1 : 1), tsin, tcos, te);
+            const float c0 = __shfl(cc, 0), c2 = __shfl(cc, 1);
+            if (tid == 0) {
+                const float c1 = best;
+                const float denom = 2.0f * (c0 - 2.0f * c1 + c2);
+                int bp = best_pos;
+                if (fabs_(denom) > 1e-10f) {
+                    float delta = fdiv(c0 - c2, denom);
+                    const float lo = (1.0f < delta) ? 1.0f : delta;
+                    delta = (-1.0f < lo) ? lo : -1.0f;
+                    bp = static_cast<int>(__builtin_roundf(static_cast<float>(best_pos) + delta));
+                }
+                spos = bp;
             }
+            __syncthreads();
+            best_pos = spos;
         }
         pos_out = (best >= A.threshold) ? best_pos : -1;
     }
-    if (lane == 0) { s.corr = best; s.pos = pos_out; }
+    if (tid == 0) { s.corr = best; s.pos = pos_out; }
+    (void)sbest;
 }
 
 // CFO and position correction from the two detections (:454-509)

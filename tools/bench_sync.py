@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Throughput of the acquisition / MC-DPSK kernels on synthetic buffers (SURVEY.md §8d C4, C1 shapes).
+Prints one JSON object; not the contract bench (bench.py is)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ria_amd.engine import RxEngine
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    e = RxEngine("QAM16", "R1_2")
+    rng = np.random.default_rng(1)
+    res = {}
+    # ZC: preamble (2512) at a random offset of a 4512-sample noisy buffer
+    pre = e.zc_preamble(5)
+    n = 20000
+    base = torch.randn((n, 4512), device="cuda") * 0.2
+    offs = rng.integers(0, 2000, n)
+    pt = torch.from_numpy(pre).cuda()
+    for i in range(0, n, 1):
+        pass
+    idx = torch.from_numpy(offs).cuda()[:, None] + torch.arange(2512, device="cuda")[None, :]
+    base.scatter_add_(1, idx, pt[None, :].expand(n, -1))
+    t = timed(lambda: e.sync_zc(base, 0.3, 15))
+    r = e.sync_zc(base, 0.3, 15)
+    res["zc"] = {"buffers": n, "samples": 4512, "ms": round(t * 1e3, 2), "preambles_per_s": round(n / t), "detected": int(r["detected"].sum()),
+                 "GBps_algorithmic": round(n * 4512 * 4 / t / 1e9, 2)}
+    # dual chirp: 57600-sample preamble in 120000-sample buffers
+    ch = torch.from_numpy(e.chirp_preamble()).cuda()
+    n = 256
+    buf = torch.randn((n, 120000), device="cuda") * 0.1
+    offs = rng.integers(0, 62000, n)
+    idx = torch.from_numpy(offs).cuda()[:, None] + torch.arange(57600, device="cuda")[None, :]
+    buf.scatter_add_(1, idx, ch[None, :].expand(n, -1))
+    t = timed(lambda: e.sync_chirp(buf, 0.15))
+    r = e.sync_chirp(buf, 0.15)
+    exact = int((r["up_chirp_start"] == offs).sum())
+    res["chirp"] = {"buffers": n, "samples": 120000, "ms": round(t * 1e3, 2), "preambles_per_s": round(n / t), "success": int(r["success"].sum()),
+                    "up_start_exact": exact, "GBps_algorithmic": round(n * 120000 * 4 / t / 1e9, 2)}
+    # LTS light sync on 21000-sample spans of noise (worst case: full search)
+    n = 4000
+    x = torch.randn((n, 21000), device="cuda") * 0.1
+    t = timed(lambda: e.sync_lts(x, None, 0.5))
+    res["lts"] = {"buffers": n, "samples": 21000, "ms": round(t * 1e3, 2), "spans_per_s": round(n / t)}
+    # MC-DPSK: C1 shape, 10 carriers DBPSK, one codeword (74 symbols)
+    n = 8000
+    x = torch.randn((n, 74 * 512), device="cuda") * 0.1
+    t = timed(lambda: e.mcdpsk_demod(x, 10, 1, 1))
+    res["mcdpsk"] = {"frames": n, "samples": 74 * 512, "ms": round(t * 1e3, 2), "frames_per_s": round(n / t),
+                     "GBps_algorithmic": round(n * 74 * 512 * 4 / t / 1e9, 2)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
