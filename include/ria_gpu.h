@@ -241,6 +241,12 @@ typedef struct ria_lts_result {
 int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
                            const float* known_cfo_dev, float threshold, ria_lts_result* out_dev, void* stream);
 
+/* Single-buffer convenience forms for the IWaveform adaptor (host memory in, result by value; they stage
+ * through device memory and synchronise).  kind: 0 dual chirp (ria_chirp_result), 1 LTS light sync
+ * (ria_lts_result), 2 ZC (ria_zc_result); param = known CFO in Hz (kinds 1, 2), root_mask only for kind 2. */
+int ria_gpu_sync_host(ria_gpu_handle h, int kind, const float* samples_host, int n_samples, float threshold, float param,
+                      uint32_t root_mask, void* result_out /* 32 bytes */);
+
 /* ---- MC-DPSK demodulator (src/psk/multi_carrier_dpsk.hpp) and HARQ chase combine (src/fec/chase_cache.cpp)
  * ria_gpu_mcdpsk_demod_batch replaces MultiCarrierDPSKDemodulator as MCDPSKWaveform::process drives it after
  * an external chirp detection (setChirpDetected + process, multi_carrier_dpsk.hpp:797-896): each frame is

@@ -47,7 +47,7 @@ struct ria_gpu {
     void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
     int ch_chunk = 0;
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
-    std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
+    std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
     void* d_demod_const = nullptr;
     void* d_tx_const = nullptr;
@@ -362,6 +362,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     for (auto& kv : h->d_mc_mixer) if (kv.second) (void)hipFree(kv.second);
     if (h->d_mc_hilbert) (void)hipFree(h->d_mc_hilbert);
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
+    if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
@@ -895,6 +896,32 @@ int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t s
     A.threshold = threshold; A.hilbert = static_cast<const float*>(h->d_hilbert65); A.out = out_dev;
     hipLaunchKernelGGL(lts_sync_kernel, dim3(n_buffers), dim3(256), lts_lds_bytes(), static_cast<hipStream_t>(stream), A);
     HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_sync_host(ria_gpu_handle h, int kind, const float* samples_host, int n_samples, float threshold, float param,
+                      uint32_t root_mask, void* result_out) {
+    if (!h || !samples_host || !result_out || n_samples < 0 || kind < 0 || kind > 2) return RIA_ERR_INVALID;
+    const size_t need = static_cast<size_t>(n_samples) * sizeof(float) + 64;
+    if (need > h->sync_host_bytes) {
+        if (h->d_sync_host) (void)hipFree(h->d_sync_host);
+        h->d_sync_host = nullptr; h->sync_host_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_sync_host, need));
+        h->sync_host_bytes = need;
+    }
+    unsigned char* base = static_cast<unsigned char*>(h->d_sync_host);
+    float* d_param = reinterpret_cast<float*>(base);
+    void* d_res = base + 16;
+    float* d_x = reinterpret_cast<float*>(base + 64);
+    HIP_TRY(h, hipMemcpy(d_x, samples_host, static_cast<size_t>(n_samples) * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_param, &param, sizeof(float), hipMemcpyHostToDevice));
+    int rc;
+    if (kind == 0) rc = ria_gpu_sync_chirp_batch(h, d_x, n_samples, n_samples, 1, threshold, static_cast<ria_chirp_result*>(d_res), nullptr);
+    else if (kind == 1) rc = ria_gpu_sync_lts_batch(h, d_x, n_samples, n_samples, 1, d_param, threshold, static_cast<ria_lts_result*>(d_res), nullptr);
+    else rc = ria_gpu_sync_zc_batch(h, d_x, n_samples, n_samples, 1, threshold, root_mask, d_param, static_cast<ria_zc_result*>(d_res), nullptr);
+    if (rc != RIA_OK) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(result_out, d_res, 32, hipMemcpyDeviceToHost));
     return RIA_OK;
 }
 

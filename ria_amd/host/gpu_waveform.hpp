@@ -118,6 +118,37 @@ public:
         synced_ = true;
         return soft_bits_.size() >= 648;
     }
+    // detectSync(): dual-chirp acquisition (ofdm_chirp_waveform.cpp:162-205 on top of detectDualChirp)
+    bool detectSync(SampleSpan samples, SyncResult& result, float threshold = 0.15f) {
+        ria_chirp_result r{};
+        if (ria_gpu_sync_host(gpu_->get(), 0, samples.data(), static_cast<int>(samples.size()), threshold, 0.0f, 0u, &r) != RIA_OK) return false;
+        result.detected = r.success != 0;
+        result.correlation = std::max(r.up_correlation, r.down_correlation);
+        result.cfo_hz = r.cfo_hz;
+        result.has_training = true;
+        if (r.success) {
+            synced_ = true; last_cfo_ = r.cfo_hz;
+            result.start_sample = r.down_chirp_start + 24000 + 4800;   // training starts after the down chirp + gap
+            training_start_ = static_cast<size_t>(result.start_sample);
+        }
+        return result.detected;
+    }
+    // detectDataSync(): LTS light sync of connected-mode DATA frames (ofdm_chirp_waveform.cpp:207-384)
+    bool detectDataSync(SampleSpan samples, SyncResult& result, float known_cfo_hz = 0.0f, float threshold = 0.5f) {
+        ria_lts_result r{};
+        result.detected = false; result.correlation = 0.0f; result.cfo_hz = known_cfo_hz; result.has_training = true;
+        if (ria_gpu_sync_host(gpu_->get(), 1, samples.data(), static_cast<int>(samples.size()), threshold, known_cfo_hz, 0u, &r) != RIA_OK) return false;
+        result.correlation = r.correlation;
+        burst_marker_ = false;
+        if (r.detected) {
+            result.detected = true; result.start_sample = r.start_sample;
+            training_start_ = static_cast<size_t>(r.start_sample);
+            synced_ = true; last_cfo_ = known_cfo_hz;
+            burst_marker_ = r.burst_interleaved != 0;
+        }
+        return result.detected;
+    }
+    bool wasBurstInterleaved() const { return burst_marker_; }
     std::vector<float> getSoftBits() { return std::move(soft_bits_); }                // :135
     void reset() { soft_bits_.clear(); synced_ = false; has_abs_ = false; abs_pos_ = 0; }  // CFO preserved (:474-485)
     bool isSynced() const { return synced_; }

@@ -19,6 +19,13 @@ int main(int argc, char** argv) {
     GpuOfdmChirpWaveform rx(mod, rate);
     GpuHandle dec(mod, rate);
     rx.reset();
+    if (argc > 7) {   // sync mode: detectDataSync / detectSync on the span, print the SyncResult, exit
+        SyncResult r;
+        bool ok = (atoi(argv[7]) == 1) ? rx.detectDataSync(SampleSpan{x.data(), x.size()}, r, static_cast<float>(atof(argv[4])), 0.5f)
+                                       : rx.detectSync(SampleSpan{x.data(), x.size()}, r, 0.15f);
+        printf("%d %d %.9g %.9g %d\n", ok ? 1 : 0, r.start_sample, r.correlation, r.cfo_hz, rx.wasBurstInterleaved() ? 1 : 0);
+        return 0;
+    }
     rx.setAbsoluteTrainingPosition(static_cast<size_t>(atoll(argv[5])));
     rx.setFrequencyOffset(static_cast<float>(atof(argv[4])));
     bool ready = rx.process(SampleSpan{x.data(), x.size()});

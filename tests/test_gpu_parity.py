@@ -520,3 +520,20 @@ def test_cpp_host_adaptor_drop_in(golden, tmp_path):
             assert int(t[0]) == g["dec_ok"][f][cw]
             if int(t[0]):
                 assert np.array_equal(np.array(t[2:], np.uint8), g["dec_data"][f][cw * 40:(cw + 1) * 40])
+    # IWaveform::detectDataSync and detectSync through the adaptor (single-buffer host forms of the sync ABI)
+    gl = golden("lts_sync")
+    for i in (1, 4, 3):
+        fin = str(tmp_path / f"lts{i}.f32")
+        gl["buffers"][i].tofile(fin)
+        t = subprocess.check_output([exe, "6", "2", fin, repr(float(gl["cfo"][i])), "0", "x", "1"]).decode().split()
+        r = gl["results"][i]
+        assert int(t[0]) == int(r[0]) and np.float32(float(t[2])) == r[2]
+        if int(t[0]):
+            assert int(t[1]) == int(r[1]) and int(t[4]) == int(r[3])
+    from test_oracle_golden import _chirp_cases
+    e = engine("QAM16", "R1_2")
+    x, r = _chirp_cases(golden, e.chirp_preamble())[0]
+    fin = str(tmp_path / "chirp0.f32")
+    x.tofile(fin)
+    t = subprocess.check_output([exe, "6", "2", fin, "0", "0", "x", "0"]).decode().split()
+    assert int(t[0]) == 1 and int(t[1]) == int(r[2]) + 24000 + 4800 and np.float32(float(t[3])) == r[3]
