@@ -128,16 +128,18 @@ __device__ __forceinline__ float minf_(float a, float b) { return (b < a) ? b : 
 // front to back (contiguous 16-byte LDS reads, `count` dependent adds) while the other N-1 sums run
 // in the neighbouring lanes; results are broadcast with readlane.
 // Non-members / ordinals >= count contribute nothing (the accumulator starts at +0 and never becomes -0).
+constexpr int kSumRow = 68;
 template <int N, int MAXC>
 __device__ __forceinline__ void ordered_sums(const float (&terms)[N], bool member, int ord, int count, float* T,
                                              int lane, float (&out)[N]) {
-    static_assert(N <= 8 && MAXC % 4 == 0 && MAXC <= 64, "scratch is [8][64]");
+    static_assert(N <= 8 && MAXC % 4 == 0 && MAXC <= 64, "scratch is [8][kSumRow]");
     if (member) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) T[k * 64 + ord] = terms[k];
+        for (int k = 0; k < N; ++k) T[k * kSumRow + ord] = terms[k];
     }
     wave_sync();
-    const float4* row = reinterpret_cast<const float4*>(T + (lane & 7) * 64);
+    // rows are 68 floats apart: a stride of 64 would put the 8 rows read by one ds_read_b128 on the same banks
+    const float4* row = reinterpret_cast<const float4*>(T + (lane & 7) * kSumRow);
     float4 v[MAXC / 4];
 #pragma unroll
     for (int q = 0; q < MAXC / 4; ++q) v[q] = row[q];
@@ -364,7 +366,7 @@ struct DemodShared {
     int rerun, pad_;
     float sym_theta[64];        // correction phase at the first sample of each symbol
     float sub_theta[16];        // ... and at every 72nd sample of the symbol being staged
-    float sums[8 * 64];         // ordered_sums scratch (16-byte aligned: see offset of this member)
+    float sums[8 * 68];         // ordered_sums scratch [8][kSumRow] (16-byte aligned: see offset of this member)
 };
 
 // One step of the CFO correction phase (channel_equalizer.cpp:139-144): th += inc, wrapped with

@@ -119,6 +119,7 @@ struct FastCode {
 #ifndef RIA_ADDTID
 #define RIA_ADDTID 0
 #endif
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr bool kCvRegs = RIA_CV_REGS != 0;
 constexpr bool kAddTid = RIA_ADDTID != 0;
 
@@ -310,6 +311,8 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
         lo = -50.0f; hi = 50.0f;
         wave_sync();
         // information columns: tot = llr + sum of c2v in ascending check order
+        // (v_pk_add_f32 pairing of rounds / edges was measured: fewer VALU instructions, same time -- the
+        // loop is LDS-bound as much as VALU-bound)
         static_for<0, S::NC>([&](auto R_) __attribute__((always_inline)) {
             constexpr int r = decltype(R_)::value;
             constexpr int DV = S::dv(r);
@@ -432,13 +435,19 @@ __device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, unsi
 // ------------------------------------------------------------------------------------------------ kernel P
 // first decode of every codeword (factor 0.9375): one single-wave workgroup per codeword, so the
 // hardware dispatcher balances converging (few iterations) and hopeless (80 iterations) codewords.
+// XCD-aware order: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own
+// L2, while the four codewords of a frame gather from the SAME 10 KB of interleaved soft bits; the map
+// below gives the four codewords of frame 8g+x the block ids 32g + 8cw + x, i.e. one XCD per frame.
 template <class S>
 __global__ __launch_bounds__(64) void fast_primary_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
+    const unsigned b = blockIdx.x, g = b >> 5, r = b & 31u, cw = r >> 3, x = r & 7u;
+    const unsigned frame = 8u * g + x;
+    if (frame >= static_cast<unsigned>(A.n_frames)) return;
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
-    fast_unit(st, A, smem, blockIdx.x, 0, lane);
+    fast_unit(st, A, smem, 4u * frame + cw, 0, lane);
 }
 
 // per frame: every codeword at or after the first one whose first decode failed may need the other
@@ -456,17 +465,19 @@ __global__ void fast_mark_kernel(FastDecodeArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernel Z
-// one single-wave workgroup per (list1 entry, factor 1..4); the grid is sized for the worst case and
-// surplus workgroups exit at once (the list length is only known on the device)
+// single-wave workgroups stride over the (list1 entry, factor 1..4) units: the list length is only known on
+// the device, so the grid is a fixed size and each workgroup takes units u = blockIdx, blockIdx + gridDim, ...
+// (no atomic queue: the unit -> workgroup map is static)
 template <class S>
 __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const unsigned u = blockIdx.x;
-    if (u >= A.ctl->n_list1 * 4u) return;
+    const unsigned total = A.ctl->n_list1 * 4u;
+    if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
-    fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
+    for (unsigned u = blockIdx.x; u < total; u += gridDim.x)
+        fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
 }
 
 // ------------------------------------------------------------------------------------------------ chain

@@ -266,12 +266,14 @@ __global__ void recovery_list_kernel(RecoveryArgs R) {
 template <class S>
 __global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned u = blockIdx.x;
-    if (u >= *R.n_list2) return;
+    const unsigned total = *R.n_list2;
+    if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, R.d.c, smem, threadIdx.x);
-    const unsigned e = R.list2[u];
-    fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
+    for (unsigned u = blockIdx.x; u < total; u += gridDim.x) {     // static unit -> workgroup map
+        const unsigned e = R.list2[u];
+        fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
+    }
 }
 // one workgroup per flagged frame: compact copies of everything the host stage reads
 __global__ __launch_bounds__(256) void recovery_gather_kernel(RecoveryArgs R) {

@@ -247,7 +247,7 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
     hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(n_frames * 16), dim3(64), h->wave_lds, s, R);
+        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(std::min(n_frames * 16, 16384)), dim3(64), h->wave_lds, s, R);
     });
     hipLaunchKernelGGL(recovery_search_kernel, dim3(n_frames), dim3(64), recovery_lds_bytes(h->geo.bytes_per_codeword), s, R);
     if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery kernel launch failed");
@@ -542,12 +542,12 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     };
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(fast_primary_kernel<S>, dim3(n_frames * 4), dim3(64), wb, s, A);
+        hipLaunchKernelGGL(fast_primary_kernel<S>, dim3(32 * ((n_frames + 7) / 8)), dim3(64), wb, s, A);
         stage("primary");
         hipLaunchKernelGGL(fast_mark_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
         stage("mark");
         if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB))
-            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(n_frames * 16), dim3(64), wb, s, A);
+            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, 16384)), dim3(64), wb, s, A);
         stage("phase0");
         hipLaunchKernelGGL(fast_chain_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
         stage("chain");
