@@ -32,6 +32,9 @@ FRAME_SETS = [
     ("qpsk_r12", po.QPSK, po.R1_2, [(0, 12.0, 0.0, 0), (2, 15.0, 0.0, 0)]),
     ("dqpsk_r14", po.DQPSK, po.R1_4, [(0, 6.0, 0.0, 0), (3, 10.0, 0.0, 0)]),
     ("qam16_r34", po.QAM16, po.R3_4, [(0, 22.0, 0.0, 0), (2, 25.0, 0.0, 0)]),
+    # added later: own RNG stream (5th element) so that the sets above keep their recorded draws
+    ("d8psk_r12", po.D8PSK, po.R1_2, [(0, 25.0, 0.0, 0), (2, 25.0, 0.0, 0), (1, 20.0, 1.5, 2400), (3, 24.0, 0.0, 0)], 8801),
+    ("d8psk_r14", po.D8PSK, po.R1_4, [(0, 18.0, 0.0, 0), (2, 22.0, 0.0, 0)], 8802),
 ]
 
 
@@ -125,7 +128,12 @@ def main():
     rng = np.random.default_rng(20261004)
 
     # ---- frames
-    for name, mod, rate, chans in FRAME_SETS:
+    only = os.environ.get("RIA_GOLDEN_ONLY", "")
+    for entry in FRAME_SETS:
+        name, mod, rate, chans = entry[:4]
+        if only and name not in only.split(","):
+            continue
+        rng_frames = np.random.default_rng(entry[4]) if len(entry) > 4 else rng
         rec = {}
         bytes_per_cw = {po.R1_4: 20, po.R1_2: 40, po.R2_3: 54, po.R3_4: 60, po.R5_6: 67}[rate]
         cap = 4 * bytes_per_cw - 19
@@ -133,7 +141,7 @@ def main():
         L = {k: [] for k in ("payload", "info", "coded", "tx", "rx", "llr", "aux", "h", "dec_data", "dec_ok",
                              "chan", "seq")}
         for f, (kind, snr, cfo, abs_pos) in enumerate(chans):
-            payload = rng.integers(0, 256, cap, dtype=np.uint8)
+            payload = rng_frames.integers(0, 256, cap, dtype=np.uint8)
             seq = 100 + f
             s, info, coded, bps = R.tx_frame(mod, rate, payload, seq)
             x = s * np.float32(0.8 / np.abs(s).max())  # tools/test_waveform_simple.cpp:365-371
@@ -153,6 +161,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"frames_{name}.npz"), **rec)
         print(name, "frames", len(chans), "decoded", [int(o.all()) for o in L["dec_ok"]])
 
+    if only:
+        return 0
     # ---- raw LDPC vectors per rate (encode + decode with iteration counts)
     rec = {}
     for rate in (po.R1_4, po.R1_2, po.R2_3, po.R3_4, po.R5_6):

@@ -1035,6 +1035,18 @@ static int ro_demap(int mod, cf sym, cf prev, float nv, float* o) { /* soft_dema
             o[1] = ro_clip(sc * (fabsf(dI) - fabsf(dQ)) / dm);
             return 2;
         }
+        case RO_D8PSK: { /* soft_demap.hpp:239-263 */
+            cf diff = cf_mul(sym, cf_conj(prev));
+            float pd = atan2f(diff.im, diff.re);
+            float sp = cf_abs(sym) * cf_abs(prev);
+            if (sp < 1e-6f) { o[0] = o[1] = o[2] = 0.0f; return 3; }
+            float dnv = 2.0f * nv;
+            float conf = sp / dnv;
+            o[0] = ro_clip(conf * sinf(pd));
+            o[1] = ro_clip(conf * sinf(2.0f * pd));
+            o[2] = ro_clip(conf * sinf(4.0f * pd));
+            return 3;
+        }
         default: return 0;
     }
 }
@@ -1054,9 +1066,49 @@ static int ro_demod_symbol(ro_rx* r, const cf* eq, float* soft) { /* demodulator
             r->var[i] += 0.3f * (delta * delta - r->var[i]);
         }
     }
-    if ((mod == RO_DQPSK || mod == RO_DBPSK) && !r->have_dprev) {
+    if ((mod == RO_DQPSK || mod == RO_DBPSK || mod == RO_D8PSK) && !r->have_dprev) {
         for (int i = 0; i < nd; ++i) r->dprev[i] = cf_mk(1, 0);
         r->have_dprev = 1;
+    }
+    if (mod == RO_D8PSK && r->fading_index > 0.30f) {
+        /* demodulateD8PSKTwoPass (demodulator.cpp:533-620): common phase error from the embedded DQPSK grid,
+         * half of it removed before the D8PSK demap; the corrected symbol becomes the next reference */
+        float sin_sum = 0.0f, cos_sum = 0.0f, weight_sum = 0.0f;
+        for (int i = 0; i < nd; ++i) {
+            cf prev = r->dprev[i];
+            float sp = cf_abs(eq[i]) * cf_abs(prev);
+            if (sp > 0.1f) {
+                cf diff = cf_mul(eq[i], cf_conj(prev));
+                float phase = atan2f(diff.im, diff.re);
+                float pmo = (float)(phase - M_PI / 4.0f);
+                int quadrant = (int)round((double)(pmo * 2.0f) / M_PI);
+                quadrant = ((quadrant % 4) + 4) % 4;
+                float expected = (float)(quadrant * M_PI / 2.0f + M_PI / 4.0f);
+                float error = phase - expected;
+                while (error > M_PI) error = (float)(error - 2 * M_PI);
+                while (error < -M_PI) error = (float)(error + 2 * M_PI);
+                sin_sum += sp * sinf(error);
+                cos_sum += sp * cosf(error);
+                weight_sum += sp;
+            }
+        }
+        float mean_error = (weight_sum > 0.1f) ? atan2f(sin_sum, cos_sum) : 0.0f;
+        cf pc = cf_mk(1.0f, 0.0f);
+        if (fabsf(mean_error) > 0.05f && fabsf(mean_error) < 0.26f) {
+            float ce = mean_error * 0.5f;
+            pc = cf_mk(cosf(-ce), sinf(-ce));
+        }
+        for (int i = 0; i < nd; ++i) {
+            float nv = r->cnv[i] * margin;
+            float msq = r->ema[i] * r->ema[i] + 1e-6f;
+            float nvar = r->var[i] / msq;
+            nv *= (1.0f + 10.0f * nvar);
+            cf cs = cf_mul(eq[i], pc);
+            n += ro_demap(mod, cs, r->dprev[i], nv, soft + n);
+            r->dprev[i] = cs;
+        }
+        r->snr_count++;   /* demodulator.cpp:292 */
+        return n;
     }
     for (int i = 0; i < nd; ++i) {
         float nv = r->cnv[i] * margin;

@@ -325,6 +325,18 @@ __device__ inline int demap_symbol(int mod, float2 sym, float2 prev, float nv, f
             o[1] = clip_llr(fdiv(sc * (fabs_(dI) - fabs_(dQ)), dm));
             return 2;
         }
+        case RIA_MOD_D8PSK: {   // soft_demap.hpp:239-263
+            float2 diff = cmul(sym, conj_(prev));
+            float pd = atan2f_glibc(diff.y, diff.x);
+            float sp = cabs_(sym) * cabs_(prev);
+            if (sp < 1e-6f) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; return 3; }
+            float dnv = 2.0f * nv;
+            float conf = fdiv(sp, dnv);
+            o[0] = clip_llr(conf * sinf_glibc(pd));
+            o[1] = clip_llr(conf * sinf_glibc(2.0f * pd));
+            o[2] = clip_llr(conf * sinf_glibc(4.0f * pd));
+            return 3;
+        }
         default: return 0;
     }
 }
@@ -766,8 +778,39 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 float nvar = fdiv(var, msq);
                 nv *= (1.0f + 10.0f * nvar);
                 float o[8];
-                int nb = demap_symbol(mod, eq, dprev, nv, o);
-                if (!coh) dprev = eq;
+                float2 sym = eq;
+                if (mod == RIA_MOD_D8PSK && fading > 0.30f) {
+                    // demodulateD8PSKTwoPass (demodulator.cpp:533-620): common phase error from the embedded DQPSK
+                    // grid (three ordered sums over the data carriers), half of it removed before the demap; the
+                    // corrected symbol becomes the next differential reference
+                    const double kPi = 3.14159265358979323846;
+                    float ts = 0.0f, tc = 0.0f, tw = 0.0f;
+                    const float sp = cabs_(eq) * cabs_(dprev);
+                    if (is_dat && sp > 0.1f) {
+                        const float2 diff = cmul(eq, conj_(dprev));
+                        const float phase = atan2f_glibc(diff.y, diff.x);
+                        const float pmo = static_cast<float>(static_cast<double>(phase) - kPi / static_cast<double>(4.0f));
+                        int quadrant = static_cast<int>(__builtin_round(static_cast<double>(pmo * 2.0f) / kPi));
+                        quadrant = ((quadrant % 4) + 4) % 4;
+                        const float expected = static_cast<float>(quadrant * kPi / static_cast<double>(2.0f) + kPi / static_cast<double>(4.0f));
+                        float err = phase - expected;
+                        while (static_cast<double>(err) > kPi) err = static_cast<float>(static_cast<double>(err) - 2 * kPi);
+                        while (static_cast<double>(err) < -kPi) err = static_cast<float>(static_cast<double>(err) + 2 * kPi);
+                        ts = sp * sinf_glibc(err); tc = sp * cosf_glibc(err); tw = sp;
+                    }
+                    float o3[3];
+                    { const float t3[3] = {ts, tc, tw}; ordered_sums<3, 60>(t3, is_dat, my_ord, K.n_data, T, lane, o3); }   // weak carriers add +0.0
+                    const float mean_error = (o3[2] > 0.1f) ? atan2f_glibc(o3[0], o3[1]) : 0.0f;
+                    if (fabs_(mean_error) > 0.05f && fabs_(mean_error) < 0.26f) {
+                        const float ce = mean_error * 0.5f;
+                        sym = cmul(eq, make_float2(cosf_glibc(-ce), sinf_glibc(-ce)));
+                    } else {
+                        sym = cmul(eq, make_float2(1.0f, 0.0f));
+                    }
+                    snr_count++;   // demodulator.cpp:292
+                }
+                int nb = demap_symbol(mod, sym, dprev, nv, o);
+                if (!coh) dprev = sym;
                 if (is_dat) {
                     float* dst = A.llr_out + static_cast<size_t>(frame) * A.llr_stride + ds * K.bits_per_symbol + K.ord[lane] * K.bits_per_carrier;
                     for (int b = 0; b < nb; ++b) dst[b] = o[b];

@@ -378,7 +378,7 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     if (cfg->fft_size != 1024 || cfg->num_carriers != 59 || cfg->cyclic_prefix != 128 ||
         cfg->sample_rate != 48000 || cfg->center_freq != 1500)
         return RIA_ERR_UNSUPPORTED;  // the production OFDM-CHIRP shape (types.hpp:252-268)
-    if (bits_per_carrier(cfg->modulation) == 0 || cfg->modulation == RIA_MOD_D8PSK) return RIA_ERR_UNSUPPORTED;
+    if (bits_per_carrier(cfg->modulation) == 0) return RIA_ERR_UNSUPPORTED;
     if (cfg->code_rate < RIA_RATE_1_4 || cfg->code_rate > RIA_RATE_5_6) return RIA_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) return RIA_ERR_NO_DEVICE;

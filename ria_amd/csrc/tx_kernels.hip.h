@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void tx_frames_kernel(const TxConst* __restric
     __syncthreads();
     // ---- differential pre-pass (sequential over symbols, parallel over carriers)
     const int n_sym = 2 + T->n_data_symbols, bps = T->bits_per_symbol, bcar = T->bits_per_carrier;
-    const bool diff = (mod == RIA_MOD_DBPSK || mod == RIA_MOD_DQPSK);
+    const bool diff = (mod == RIA_MOD_DBPSK || mod == RIA_MOD_DQPSK || mod == RIA_MOD_D8PSK);
     if (diff && tid < T->n_data) {
         float2 prev = make_float2(1.0f, 0.0f);
         for (int d = 0; d < T->n_data_symbols; ++d) {
@@ -240,7 +240,11 @@ __global__ __launch_bounds__(256) void tx_frames_kernel(const TxConst* __restric
                 for (int b = 0; b < bcar; ++b) v = (v << 1) | ((b0 + b < 2592) ? bits[b0 + b] : 0);
                 float2 pc;
                 if (mod == RIA_MOD_DBPSK) pc = (v & 1) ? make_float2(-1, 0) : make_float2(1, 0);
-                else { const float pr[4] = {1, 0, -1, 0}, pi[4] = {0, 1, 0, -1}; pc = make_float2(pr[v & 3], pi[v & 3]); }
+                else if (mod == RIA_MOD_D8PSK) {   // natural-binary octant + 22.5 deg offset (modulator.cpp D8PSK branch)
+                    const float pi_f = 3.14159265358979f;
+                    const float angle = static_cast<float>(v & 7) * fdiv(pi_f, 4.0f) + fdiv(pi_f, 8.0f);
+                    pc = make_float2(cosf_glibc(angle), sinf_glibc(angle));
+                } else { const float pr[4] = {1, 0, -1, 0}, pi[4] = {0, 1, 0, -1}; pc = make_float2(pr[v & 3], pi[v & 3]); }
                 prev = cmul(prev, pc);
                 dstate[d * 64 + tid] = prev;
             } else dstate[d * 64 + tid] = make_float2(0, 0);

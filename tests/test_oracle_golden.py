@@ -7,7 +7,7 @@ import pytest
 
 import pyoracle as po
 
-FRAME_SETS = ["qam16_r12", "dqpsk_r12", "qam64_r34", "qam32_r34", "qpsk_r12", "dqpsk_r14", "qam16_r34"]
+FRAME_SETS = ["qam16_r12", "dqpsk_r12", "qam64_r34", "qam32_r34", "qpsk_r12", "dqpsk_r14", "qam16_r34", "d8psk_r12", "d8psk_r14"]
 
 
 def bits_equal(a, b):
