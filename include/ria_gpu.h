@@ -296,6 +296,11 @@ void ria_link_data_mode(float snr_db, int waveform, float fading_index, ria_link
 int ria_link_ofdm_code_rate(float snr_db, float fading_index);                                     /* selectOFDMCodeRate */
 int ria_link_cap_initial_rate(float snr_db, float fading_index, int candidate_rate);               /* capInitialOFDMRate */
 
+/* LDPCEncoder::encode for n_cw codewords on the host (src/fec/ldpc_encoder.cpp:193-257): info = n_cw * ceil(k/8)
+ * bytes (MSB first), coded_out = n_cw * 81 bytes.  Used to synthesise MC-DPSK frames (the OFDM TX kernel
+ * encodes on the device). */
+int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, uint8_t* coded_out);
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

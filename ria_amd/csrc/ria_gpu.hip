@@ -1009,6 +1009,27 @@ void ria_link_data_mode(float snr_db, int waveform, float fading_index, ria_link
 int ria_link_ofdm_code_rate(float snr_db, float fading_index) { return select_ofdm_code_rate(snr_db, fading_index); }
 int ria_link_cap_initial_rate(float snr_db, float fading_index, int candidate_rate) { return cap_initial_ofdm_rate(snr_db, fading_index, candidate_rate); }
 
+int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, uint8_t* coded_out) {
+    if (!h || !info || !coded_out || n_cw < 0) return RIA_ERR_INVALID;
+    const LdpcCode& c = h->code;
+    const int kb = (c.k + 7) / 8;
+    std::vector<uint8_t> bits(648);
+    for (int w = 0; w < n_cw; ++w) {
+        const uint8_t* in = info + static_cast<size_t>(w) * kb;
+        for (int j = 0; j < c.k; ++j) bits[j] = (in[j >> 3] >> (7 - (j & 7))) & 1;
+        for (int i = 0; i < c.m; ++i) {   // H = [H_data | I]: parity i = XOR of the information bits of row i
+            int p = 0;
+            const auto& row = c.rows[i];
+            for (size_t s2 = 0; s2 + 1 < row.size(); ++s2) p ^= bits[row[s2]];
+            bits[c.k + i] = static_cast<uint8_t>(p);
+        }
+        uint8_t* out = coded_out + static_cast<size_t>(w) * 81;
+        std::memset(out, 0, 81);
+        for (int j = 0; j < 648; ++j) out[j >> 3] |= static_cast<uint8_t>(bits[j] << (7 - (j & 7)));
+    }
+    return RIA_OK;
+}
+
 int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n, float* out_dev,
                        void* stream) {
     if (!h || !a_dev || !out_dev || n < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_debug_math: bad argument");

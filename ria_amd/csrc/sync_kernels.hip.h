@@ -306,13 +306,19 @@ __global__ __launch_bounds__(64) void chirp_cumsum_kernel(ChirpArgs A) {
     const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
     float c = 0.0f;
     if (lane == 0) cum[0] = 0.0f;
-    for (int base = 0; base < fft_in; base += 256) {
+    float nx[4];   // next tile, loaded one iteration ahead so that the HBM latency hides behind the serial walk
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = base + 64 * q + lane;
-            const float v = (i < fft_in) ? x[i] : 0.0f;
-            sq[64 * q + lane] = v * v;
+    for (int q = 0; q < 4; ++q) { const int i = 64 * q + lane; nx[q] = (i < fft_in) ? x[i] : 0.0f; }
+    for (int base = 0; base < fft_in; base += 256) {
+        float cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nx[q];
+        if (base + 256 < fft_in) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = base + 256 + 64 * q + lane; nx[q] = (i < fft_in) ? x[i] : 0.0f; }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sq[64 * q + lane] = cur[q] * cur[q];
         wave_lds_fence();
         if (lane == 0) {
             // register blocks of 32 samples: the loads of a block do not wait for the stores of the previous
@@ -449,6 +455,7 @@ __device__ inline float chirp_td_corr(const float* x, int n, int offset, const f
     if (offset < 0 || offset + kChLen > n) return 0.0f;
     float ci = 0.0f, cq = 0.0f, e = 0.0f;
     const float* p = x + offset;
+#pragma unroll 8
     for (int i = 0; i < kChLen; ++i) {
         const float v = p[i];
         ci += v * tcos[i];

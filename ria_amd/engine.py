@@ -133,6 +133,13 @@ class RxEngine:
                                                        _ptr(out), _ptr(ok), _ptr(it), _stream_ptr()))
         return out, ok, it
 
+    def ldpc_encode(self, info):
+        """LDPCEncoder::encode on the host: info uint8 [n_cw, ceil(k/8)] -> coded uint8 [n_cw, 81]."""
+        info = np.ascontiguousarray(info, np.uint8)
+        out = np.zeros((info.shape[0], 81), np.uint8)
+        self._check(self.lib.ria_gpu_ldpc_encode_host(self.h, info.ctypes.data, info.shape[0], out.ctypes.data))
+        return out
+
     def make_frames(self, seed, first_seq, n):
         info = torch.empty((n, self.geo.info_bytes_per_frame), dtype=torch.uint8, device=self.device)
         self._check(self.lib.ria_gpu_make_frames(self.h, int(seed), int(first_seq), n, _ptr(info), _stream_ptr()))
