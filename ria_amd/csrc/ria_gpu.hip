@@ -45,7 +45,7 @@ struct ria_gpu {
     // dual-chirp acquisition: tables (built at first use) and the per-chunk workspace
     void* d_ch_tw = nullptr; void* d_ch_tmpl = nullptr; void* d_ch_tmpl_fft = nullptr; float ch_energy[2] = {0, 0};
     void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
-    int ch_chunk = 0;
+    int ch_chunk = 0, ch_outer = 0;
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
     std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
@@ -801,18 +801,22 @@ __global__ void chirp_template_conj_kernel(const float2* src, float2* dst) {
     if (i < kChFft) dst[i] = make_float2(src[i].x, -src[i].y);
 }
 
-static int chirp_prepare(ria_gpu_handle h, int chunk, hipStream_t s) {
+static int chirp_prepare(ria_gpu_handle h, int chunk, int outer, hipStream_t s) {
     hipError_t e;
 #define C_TRY(expr) if ((e = (expr)) != hipSuccess) return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e))
     if (chunk > h->ch_chunk) {
-        for (void** p : {&h->d_ch_w1, &h->d_ch_w2, &h->d_ch_mag, &h->d_ch_cum, &h->d_ch_st}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (void** p : {&h->d_ch_w1, &h->d_ch_w2, &h->d_ch_mag}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         const size_t c = static_cast<size_t>(chunk);
         C_TRY(hipMalloc(&h->d_ch_w1, c * kChFft * sizeof(float2)));
         C_TRY(hipMalloc(&h->d_ch_w2, c * kChFft * sizeof(float2)));
         C_TRY(hipMalloc(&h->d_ch_mag, c * kChFft * sizeof(float)));
-        C_TRY(hipMalloc(&h->d_ch_cum, c * (kChFft + 1) * sizeof(float)));
-        C_TRY(hipMalloc(&h->d_ch_st, c * sizeof(ChirpBufState)));
         h->ch_chunk = chunk;
+    }
+    if (outer > h->ch_outer) {
+        for (void** p : {&h->d_ch_cum, &h->d_ch_st}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        C_TRY(hipMalloc(&h->d_ch_cum, static_cast<size_t>(outer) * (kChFft + 1) * sizeof(float)));
+        C_TRY(hipMalloc(&h->d_ch_st, static_cast<size_t>(outer) * sizeof(ChirpBufState)));
+        h->ch_outer = outer;
     }
     if (!h->d_ch_tw) {
         ChirpTables t = build_chirp_tables();
@@ -843,9 +847,12 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
     if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || stride < buf_len)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_chirp_batch: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // chunk size: 3.5 MiB of workspace per buffer; 64 buffers = 224 MiB stays within the 256 MiB Infinity Cache
-    const int chunk = std::min(n_buffers, 64);
-    int rc = chirp_prepare(h, chunk, s);
+    // Two levels of chunking.  The FFT workspace (2.5 MiB per buffer) is sized for 64 buffers so that it stays
+    // within the 256 MiB Infinity Cache across the eight passes of a transform pair.  The serial pieces (energy
+    // cumsum: one wave per buffer; time-domain fallback) are latency-bound and want as many buffers in flight as
+    // possible, so they run once per OUTER chunk of up to 2048 buffers (0.5 MiB of running sums each).
+    const int chunk = std::min(n_buffers, 64), outer = std::min(n_buffers, 2048);
+    int rc = chirp_prepare(h, chunk, outer, s);
     if (rc != RIA_OK) return rc;
     ChirpArgs A{};
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.threshold = threshold;
@@ -853,18 +860,22 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
     A.tmpl = static_cast<const float*>(h->d_ch_tmpl); A.tmpl_energy[0] = h->ch_energy[0]; A.tmpl_energy[1] = h->ch_energy[1];
     A.w1 = static_cast<float2*>(h->d_ch_w1); A.w2 = static_cast<float2*>(h->d_ch_w2); A.mag = static_cast<float*>(h->d_ch_mag);
     A.cum = static_cast<float*>(h->d_ch_cum); A.st = static_cast<ChirpBufState*>(h->d_ch_st); A.out = out_dev;
-    for (int first = 0; first < n_buffers; first += chunk) {
-        const int nb = std::min(chunk, n_buffers - first);
+    for (int first = 0; first < n_buffers; first += outer) {
+        const int nb = std::min(outer, n_buffers - first);
         A.first = first; A.n_buffers = nb;
         for (int down = 0; down < 2; ++down) {
-            A.down = down;
+            A.down = down; A.sub = 0; A.n_sub = nb;
             hipLaunchKernelGGL(chirp_window_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
             hipLaunchKernelGGL(chirp_cumsum_kernel, dim3(nb), dim3(64), 0, s, A);
-            chirp_fft_forward(A, nb, s, true, true);
-            chirp_fft_inverse_mag(A, nb, s);
-            hipLaunchKernelGGL(chirp_peak_kernel, dim3(nb), dim3(256), 0, s, A);
             if (down) hipLaunchKernelGGL(chirp_td_kernel, dim3(nb), dim3(256), 0, s, A);
+            for (int sub = 0; sub < nb; sub += chunk) {
+                A.sub = sub; A.n_sub = std::min(chunk, nb - sub);
+                chirp_fft_forward(A, A.n_sub, s, true, true);
+                chirp_fft_inverse_mag(A, A.n_sub, s);
+                hipLaunchKernelGGL(chirp_peak_kernel, dim3(A.n_sub), dim3(256), 0, s, A);
+            }
         }
+        A.sub = 0; A.n_sub = nb;
         hipLaunchKernelGGL(chirp_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
     }
     HIP_TRY(h, hipGetLastError());

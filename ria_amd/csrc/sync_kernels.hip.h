@@ -233,7 +233,8 @@ struct ChirpBufState {      // per buffer, device memory
     int up_pos; float up_corr;
 };
 struct ChirpArgs {
-    const float* samples; long long stride; int buf_len; int n_buffers; int first;   // chunk = buffers [first, first+n_buffers)
+    const float* samples; long long stride; int buf_len; int n_buffers; int first;   // outer chunk = buffers [first, first+n_buffers): state + cumsum arrays
+    int sub, n_sub;            // inner chunk [sub, sub+n_sub) of the outer chunk: owns the FFT workspace slots 0..n_sub-1
     float threshold;
     const float2* tw;          // [65536]
     const float2* tmpl_fft;    // [2][131072] conj(FFT(template)): up, down
@@ -241,8 +242,8 @@ struct ChirpArgs {
     float tmpl_energy[2];
     float2* w1; float2* w2;    // [chunk][131072]
     float* mag;                // [chunk][131072]
-    float* cum;                // [chunk][131073]
-    ChirpBufState* st;         // [chunk]
+    float* cum;                // [outer chunk][131073]
+    ChirpBufState* st;         // [outer chunk]
     ria_chirp_result* out;     // [all buffers]
     int down;                  // stage: 0 up, 1 down
 };
@@ -358,8 +359,8 @@ __global__ __launch_bounds__(64) void chirp_cumsum_kernel(ChirpArgs A) {
 template <int G, int S0, int MODE, bool INV>
 __global__ __launch_bounds__(256) void chirp_fft_pass(ChirpArgs A, const float2* __restrict__ src_all, float2* __restrict__ dst_all) {
     constexpr int R = 1 << G;
-    const int b = blockIdx.y;
-    const ChirpBufState s = A.st[b];
+    const int b = blockIdx.y;                       // workspace slot; buffer A.first + A.sub + b
+    const ChirpBufState s = A.st[A.sub + b];
     if (s.active != 1) return;
     const int t = blockIdx.x * 256 + threadIdx.x;    // < N / R
     float2* dst = dst_all + static_cast<size_t>(b) * kChFft;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void chirp_fft_pass(ChirpArgs A, const float2*
         const int hi = ch_bitrev(t, TB);
         idx0 = hi * R; stridej = 1;
         if constexpr (MODE == 1) {
-            const float* in = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
+            const float* in = A.samples + static_cast<long long>(A.first + A.sub + b) * A.stride + s.win_start;
             const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
 #pragma unroll
             for (int m = 0; m < R; ++m) {
@@ -421,11 +422,11 @@ __global__ __launch_bounds__(256) void chirp_fft_pass(ChirpArgs A, const float2*
 // first maximum of |corr[pos]| / sqrt(sig_energy * tmpl_energy) over pos < search_len (:677-693)
 __global__ __launch_bounds__(256) void chirp_peak_kernel(ChirpArgs A) {
     __shared__ float sv[4]; __shared__ int si[4];
-    const int b = blockIdx.x;
-    ChirpBufState& s = A.st[b];
+    const int b = blockIdx.x;                       // workspace slot
+    ChirpBufState& s = A.st[A.sub + b];
     if (s.active != 1) return;
     const float* mag = A.mag + static_cast<size_t>(b) * kChFft;
-    const float* cum = A.cum + static_cast<size_t>(b) * (kChFft + 1);
+    const float* cum = A.cum + static_cast<size_t>(A.sub + b) * (kChFft + 1);
     const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
     const int search_len = fft_in - kChLen;
     const float te = A.tmpl_energy[A.down];

@@ -37,7 +37,7 @@ def main():
                  "GBps_algorithmic": round(n * 4512 * 4 / t / 1e9, 2)}
     # dual chirp: 57600-sample preamble in 120000-sample buffers
     ch = torch.from_numpy(e.chirp_preamble()).cuda()
-    n = 256
+    n = 2048
     buf = torch.randn((n, 120000), device="cuda") * 0.1
     offs = rng.integers(0, 62000, n)
     idx = torch.from_numpy(offs).cuda()[:, None] + torch.arange(57600, device="cuda")[None, :]
