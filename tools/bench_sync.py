@@ -58,6 +58,16 @@ def main():
     t = timed(lambda: e.mcdpsk_demod(x, 10, 1, 1))
     res["mcdpsk"] = {"frames": n, "samples": 74 * 512, "ms": round(t * 1e3, 2), "frames_per_s": round(n / t),
                      "GBps_algorithmic": round(n * 74 * 512 * 4 / t / 1e9, 2)}
+    # config C2: OFDM DQPSK R1/2, 10 000 frames, AWGN, FFT + LLR kernels only (ria_gpu_demod_batch)
+    e2 = RxEngine("DQPSK", "R1_2", max_batch=10000)
+    n = 10000
+    info = e2.make_frames(7, 0, n)
+    x = e2.tx(info, peak=0.8)
+    e2.channel_(x, 0, 15.0, 7, first_frame=0)
+    t = timed(lambda: e2.demod(x, want_status=False))
+    fs = int(e2.geo.frame_samples)
+    res["c2_dqpsk_demod"] = {"frames": n, "samples": fs, "ms": round(t * 1e3, 2), "frames_per_s": round(n / t),
+                             "GBps_algorithmic": round(n * (fs * 4 + int(e2.geo.llrs_per_frame) * 4) / t / 1e9, 2)}
     print(json.dumps(res))
 
 
