@@ -244,6 +244,9 @@ struct RecoveryArgs {
     unsigned int* flagged;       // [n_frames] frame indices needing recovery
     unsigned int* n_list2;       // counter
     unsigned int* list2;         // [16*n_frames] (fc << 3) | factor index
+    unsigned int* n_stage2;      // counter
+    unsigned int* stage2;        // [n_frames] frames whose stage 1 failed
+    int list_units_now;          // recovery_list_kernel also lists the missing re-decodes (host-search path)
     // host-search staging (RIA_RECOVERY_HOST=1 only)
     uint8_t* info_c;             // [n_flagged][4*bpc]
     float* rows_c;               // [n_flagged][4][648] decoder-order LLRs
@@ -257,6 +260,7 @@ __global__ void recovery_list_kernel(RecoveryArgs R) {
     int frame = blockIdx.x * blockDim.x + threadIdx.x;
     if (frame >= R.d.n_frames || !R.d.status[frame].needs_recovery) return;
     R.flagged[atomicAdd(R.n_flagged, 1u)] = static_cast<unsigned>(frame);
+    if (!R.list_units_now) return;     // device path: only frames whose stage 1 fails ask for the re-decodes
     for (int cw = 0; cw < 4; ++cw) {
         unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
         for (int f = 1; f <= 4; ++f)
@@ -299,57 +303,88 @@ __global__ __launch_bounds__(256) void recovery_gather_kernel(RecoveryArgs R) {
 
 __host__ __device__ inline int recovery_lds_bytes(int bpc) { return 1024 + 4 * bpc * 8 * 8 + 192 * 4 + 64; }
 
-// one wave per flagged frame: stage 1, then stage 2 from the factor result table; writes the frame's
-// payload bytes and status in place
-__global__ __launch_bounds__(64) void recovery_search_kernel(RecoveryArgs R) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned q = blockIdx.x;
-    if (q >= *R.n_flagged) return;
-    const unsigned frame = R.flagged[q];
-    const int lane = threadIdx.x;
-    const int bpc = R.d.c.bytes_per_cw;
-    RecCtx x;
+// ---- device path: stage 1 for every flagged frame; the frames it cannot recover queue the re-decodes the
+// fallback needs; stage 2 runs for those only, after recovery_fill_kernel
+__device__ inline void rec_setup(RecCtx& x, unsigned char* smem, const RecoveryArgs& R, int lane) {
     x.cw = smem; x.fd = smem + 272; x.trial = smem + 544;
     x.sd = reinterpret_cast<uint16_t*>(smem + 816);
     x.stack = reinterpret_cast<int*>(smem + 1024);
     x.sus = reinterpret_cast<Suspect*>(smem + 1024 + 192 * 4);
-    x.bpc = bpc; x.crc_bit = R.d.crc_bit; x.crc_init = R.d.crc_init; x.lane = lane;
-    uint8_t* info = R.d.info_out + static_cast<size_t>(frame) * 4 * bpc;
-    for (int i = lane; i < 4 * 68; i += 64) { const int c = i / 68, b = i - c * 68; x.cw[i] = (b < bpc) ? info[c * bpc + b] : 0; }
+    x.bpc = R.d.c.bytes_per_cw; x.crc_bit = R.d.crc_bit; x.crc_init = R.d.crc_init; x.lane = lane;
+}
+__device__ inline void rec_load_cw(const RecCtx& x, const uint8_t* info, int lane) {
+    for (int i = lane; i < 4 * 68; i += 64) { const int c = i / 68, b = i - c * 68; x.cw[i] = (b < x.bpc) ? info[c * x.bpc + b] : 0; }
     wave_sync();
-    const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
-    const uint16_t* gather = R.d.gather;
-    bool good = rec_search(x, [&](int c, int i) { return fl[gather[c * 648 + i]]; });
-    if (!good) {
-        // Stage 2 (frame_v2.cpp:1836-1866): factors 0.75, 0.625, 0.5, 0.875 = kFactors[2, 3, 4, 1]
-        const int forder[4] = {2, 3, 4, 1};
-        for (int at = 0; at < 4 && !good; ++at)
-            for (int c = 0; c < 4 && !good; ++c) {
-                const unsigned fc = frame * 4u + c;
-                if (R.d.res[fc].state[forder[at]] != 2) continue;
-                const uint8_t* rd = R.d.res_bytes + (static_cast<size_t>(fc) * kNumFactors + forder[at]) * bpc;
-                bool diff = false;
-                for (int b = lane; b < bpc; b += 64) diff = diff || rd[b] != x.cw[c * 68 + b];
-                if (__ballot(diff) == 0ull) continue;
-                uint8_t keep0 = 0, keep1 = 0;   // bpc <= 68 < 128: two bytes per lane
-                wave_sync();
-                if (lane < bpc) { keep0 = x.cw[c * 68 + lane]; x.cw[c * 68 + lane] = rd[lane]; }
-                if (lane + 64 < bpc) { keep1 = x.cw[c * 68 + lane + 64]; x.cw[c * 68 + lane + 64] = rd[lane + 64]; }
-                wave_sync();
-                if (rec_try(x)) { good = true; break; }
-                if (lane < bpc) x.cw[c * 68 + lane] = keep0;
-                if (lane + 64 < bpc) x.cw[c * 68 + lane + 64] = keep1;
-                wave_sync();
-            }
-    }
+}
+__device__ inline void rec_publish(const RecCtx& x, const RecoveryArgs& R, unsigned frame, uint8_t* info, bool good, int lane) {
     wave_sync();
-    for (int i = lane; i < 4 * bpc; i += 64) { const int c = i / bpc, b = i - c * bpc; info[i] = good ? x.cw[c * 68 + b] : 0; }
+    for (int i = lane; i < 4 * x.bpc; i += 64) { const int c = i / x.bpc, b = i - c * x.bpc; info[i] = good ? x.cw[c * 68 + b] : 0; }
     if (lane == 0) {
         ria_decode_status* s = R.d.status + frame;
         s->needs_recovery = 0;
         s->frame_valid = good ? 1 : 0;
         for (int c = 0; c < 4; ++c) s->cw_ok[c] = good ? 1 : 0;
     }
+}
+
+__global__ __launch_bounds__(64) void recovery_stage1_kernel(RecoveryArgs R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned q = blockIdx.x;
+    if (q >= *R.n_flagged) return;
+    const unsigned frame = R.flagged[q];
+    const int lane = threadIdx.x;
+    RecCtx x;
+    rec_setup(x, smem, R, lane);
+    uint8_t* info = R.d.info_out + static_cast<size_t>(frame) * 4 * x.bpc;
+    rec_load_cw(x, info, lane);
+    const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
+    const uint16_t* gather = R.d.gather;
+    const bool good = rec_search(x, [&](int c, int i) { return fl[gather[c * 648 + i]]; });
+    if (good) { rec_publish(x, R, frame, info, true, lane); return; }
+    if (lane == 0) {
+        R.stage2[atomicAdd(R.n_stage2, 1u)] = frame;
+        for (int cw = 0; cw < 4; ++cw) {
+            const unsigned fc = frame * 4u + cw;
+            for (int f = 1; f <= 4; ++f)
+                if (R.d.res[fc].state[f] == 0) R.list2[atomicAdd(R.n_list2, 1u)] = (fc << 3) | static_cast<unsigned>(f);
+        }
+    }
+}
+
+// Stage 2 (frame_v2.cpp:1836-1866): factors 0.75, 0.625, 0.5, 0.875 = kFactors[2, 3, 4, 1]; stage 1 left the
+// codeword bytes untouched (every failed trial is reverted), so they are re-read from the output buffer
+__global__ __launch_bounds__(64) void recovery_stage2_kernel(RecoveryArgs R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned q = blockIdx.x;
+    if (q >= *R.n_stage2) return;
+    const unsigned frame = R.stage2[q];
+    const int lane = threadIdx.x;
+    RecCtx x;
+    rec_setup(x, smem, R, lane);
+    const int bpc = x.bpc;
+    uint8_t* info = R.d.info_out + static_cast<size_t>(frame) * 4 * bpc;
+    rec_load_cw(x, info, lane);
+    bool good = false;
+    const int forder[4] = {2, 3, 4, 1};
+    for (int at = 0; at < 4 && !good; ++at)
+        for (int c = 0; c < 4 && !good; ++c) {
+            const unsigned fc = frame * 4u + c;
+            if (R.d.res[fc].state[forder[at]] != 2) continue;
+            const uint8_t* rd = R.d.res_bytes + (static_cast<size_t>(fc) * kNumFactors + forder[at]) * bpc;
+            bool diff = false;
+            for (int b = lane; b < bpc; b += 64) diff = diff || rd[b] != x.cw[c * 68 + b];
+            if (__ballot(diff) == 0ull) continue;
+            uint8_t keep0 = 0, keep1 = 0;   // bpc <= 68 < 128: two bytes per lane
+            wave_sync();
+            if (lane < bpc) { keep0 = x.cw[c * 68 + lane]; x.cw[c * 68 + lane] = rd[lane]; }
+            if (lane + 64 < bpc) { keep1 = x.cw[c * 68 + lane + 64]; x.cw[c * 68 + lane + 64] = rd[lane + 64]; }
+            wave_sync();
+            if (rec_try(x)) { good = true; break; }
+            if (lane < bpc) x.cw[c * 68 + lane] = keep0;
+            if (lane + 64 < bpc) x.cw[c * 68 + lane + 64] = keep1;
+            wave_sync();
+        }
+    rec_publish(x, R, frame, info, good, lane);
 }
 
 }  // namespace ria

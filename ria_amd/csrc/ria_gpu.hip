@@ -65,7 +65,7 @@ struct ria_gpu {
     uint8_t* d_res_bytes = nullptr;       // [4 * ws_frames][5][bytes_per_cw]
     int ws_frames = 0;
     // CRC-recovery staging (device + pinned host mirrors), sized for ws_frames
-    unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr;
+    unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr; unsigned int* d_stage2 = nullptr;
     uint8_t* d_info_c = nullptr; float* d_rows_c = nullptr; uint8_t* d_redec_ok = nullptr; uint8_t* d_redec_bytes = nullptr;
     ria_decode_status* d_st_c = nullptr;
     unsigned int* p_rctl = nullptr; unsigned int* p_flagged = nullptr; uint8_t* p_info_c = nullptr; float* p_rows_c = nullptr;
@@ -181,10 +181,11 @@ static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames, bool host_s
     hipError_t e;
 #define A_TRY(expr) if ((e = (expr)) != hipSuccess) return e
     if (n_frames > h->rec_frames) {
-        for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_stage2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_stage2), n * 4));
         h->rec_frames = n_frames;
     }
     if (host_staging && n_frames > h->rec_host_frames) {
@@ -241,15 +242,17 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
     if (e0 != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery workspace: %s", hipGetErrorString(e0));
     RecoveryArgs R{};
     R.d = D;
-    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1;
-    R.flagged = h->d_flagged; R.list2 = h->d_list2;
+    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1; R.n_stage2 = h->d_rctl + 2;
+    R.flagged = h->d_flagged; R.list2 = h->d_list2; R.stage2 = h->d_stage2; R.list_units_now = 0;
     if (hipMemsetAsync(h->d_rctl, 0, 16, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
+    const int rl = recovery_lds_bytes(h->geo.bytes_per_codeword);
     hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
+    hipLaunchKernelGGL(recovery_stage1_kernel, dim3(n_frames), dim3(64), rl, s, R);
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
         hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(std::min(n_frames * 16, 16384)), dim3(64), h->wave_lds, s, R);
     });
-    hipLaunchKernelGGL(recovery_search_kernel, dim3(n_frames), dim3(64), recovery_lds_bytes(h->geo.bytes_per_codeword), s, R);
+    hipLaunchKernelGGL(recovery_stage2_kernel, dim3(n_frames), dim3(64), rl, s, R);
     if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery kernel launch failed");
     return RIA_OK;
 }
@@ -265,7 +268,7 @@ static int run_crc_recovery_host(ria_gpu_handle h, const FastDecodeArgs& D, hipS
     RecoveryArgs R{};
     R.d = D;
     R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1;
-    R.flagged = h->d_flagged; R.list2 = h->d_list2;
+    R.flagged = h->d_flagged; R.list2 = h->d_list2; R.list_units_now = 1;
     R.info_c = h->d_info_c; R.rows_c = h->d_rows_c; R.redec_ok = h->d_redec_ok; R.redec_bytes = h->d_redec_bytes;
 #define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
     R_TRY(hipMemsetAsync(h->d_rctl, 0, 16, s));
@@ -364,7 +367,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
-    for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_info_c, (void*)h->d_rows_c,
+    for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
                     (void*)h->p_redec_bytes, (void*)h->p_st_c}) if (p) (void)hipHostFree(p);
