@@ -447,6 +447,52 @@ def test_adaptive_ladder_sweep_with_harq():
     assert rows[-5.0][5] > 96 or one_shot[1] == 0              # and it was actually exercised when needed
 
 
+def test_sync_and_mcdpsk_edge_cases(oracle):
+    """Empty batches, buffers shorter than one correlation, minimal frames, bad arguments: same answers as the
+    reference's early returns (zc_sync.hpp:202-205, chirp_sync.hpp:372-376, ofdm_chirp_waveform.cpp:221-223)."""
+    import ctypes as C
+    import torch
+    from ria_amd import capi
+    e = engine("QAM16", "R1_2")
+    rng = np.random.default_rng(1)
+    empty = torch.zeros((0, 4512), dtype=torch.float32, device="cuda")
+    assert len(e.sync_zc(empty)) == 0 and len(e.sync_chirp(torch.zeros((0, 60000), dtype=torch.float32, device="cuda"))) == 0
+    assert len(e.sync_lts(torch.zeros((0, 8000), dtype=torch.float32, device="cuda"))) == 0
+    # shorter than one ZC repetition / than a dual chirp / than three OFDM symbols
+    x = rng.normal(0, 0.1, (3, 1000)).astype(np.float32)
+    r = e.sync_zc(dev(x))
+    assert (r["detected"] == 0).all() and (r["start_sample"] == -1).all() and (r["root_detected"] == -1).all() and (r["frame_type"] == 255).all()
+    x = rng.normal(0, 0.1, (2, 52799)).astype(np.float32)
+    r = e.sync_chirp(dev(x))
+    assert (r["success"] == 0).all() and (r["up_chirp_start"] == -1).all() and (r["up_correlation"] == 0).all()
+    x = rng.normal(0, 0.1, (2, 3455)).astype(np.float32)
+    r = e.sync_lts(dev(x))
+    assert (r["detected"] == 0).all() and (r["correlation"] == 0).all()
+    # exactly one ZC repetition, all-zero buffer, constant buffer: GPU == oracle
+    for buf in (np.zeros(1016, np.float32), np.zeros(4512, np.float32), np.full(3000, 0.25, np.float32)):
+        got = e.sync_zc(dev(buf[None, :]))
+        exp = oracle.zc_detect(buf, 0.3, 15, 0.0)
+        assert int(got["detected"][0]) == int(exp[0]) and np.float32(got["correlation"][0]).view(np.uint32) == exp[3].view(np.uint32)
+    z = np.zeros(21000, np.float32)
+    got = e.sync_lts(dev(z[None, :]))
+    exp = oracle.detect_data_sync(z, 0.0, 0.5)
+    assert int(got["detected"][0]) == int(exp[0]) and np.float32(got["correlation"][0]).view(np.uint32) == exp[2].view(np.uint32)
+    # minimal MC-DPSK frame: training + reference + one data symbol
+    f = rng.normal(0, 0.2, 10 * 512).astype(np.float32)
+    llr, st = e.mcdpsk_demod(dev(f[None, :]), 10, 2, 1)
+    exp, aux = oracle.mcdpsk_demod(10, 2, 1, f)
+    assert np.array_equal(llr.cpu().numpy()[0].view(np.uint32), exp.view(np.uint32)) and int(st["n_llr"][0]) == 20
+    # argument validation: negative status, nothing launched
+    L, h = capi.load(), e.h
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert L.ria_gpu_sync_zc_batch(h, None, 4512, 4512, 1, 0.3, 15, None, C.c_void_p(out.data_ptr()), None) == -1
+    assert L.ria_gpu_sync_zc_batch(h, C.c_void_p(out.data_ptr()), 100, 4512, 1, 0.3, 15, None, C.c_void_p(out.data_ptr()), None) == -1
+    cfg = capi.McdpskConfig(10, 3, 1, 0)
+    assert L.ria_gpu_mcdpsk_demod_batch(h, C.byref(cfg), C.c_void_p(out.data_ptr()), 5120, 5120, 1, None, None, C.c_void_p(out.data_ptr()), 20,
+                                        C.c_void_p(out.data_ptr()), None) == -1
+    assert e.lib.ria_gpu_last_error(h) != b""
+
+
 def test_loopback_round_trip_full_size():
     """Size-independent property at bench scale: make_frames -> tx -> AWGN 20 dB -> rx returns the
     transmitted bytes for (nearly) every frame, and frame_valid agrees with byte equality."""
