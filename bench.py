@@ -6,7 +6,8 @@ LDPC min-sum incl. the reference's retry cascade and CRC recovery -> payload byt
 of synthetic frames that is already resident in HBM.  Workload at N=1: BASELINE.json configs[2]
 "OFDM QAM16 R1/2 + LDPC min-sum, 100k frames, Watterson moderate fading" (the configuration the
 metric is quoted on).  Frames are synthesised on the GPU by the library's own TX + channel kernels
-(untimed).  N>1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; frames
+(untimed; the channel kernel reproduces sim::WattersonChannel's random stream bit for bit, channel seed =
+base + global frame index as in tools/test_waveform_simple.cpp).  N>1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; frames
 are sharded over ranks (weak scaling, per-GPU batch fixed), RCCL only broadcasts the seed and
 all-reduces counters/timing.
 
@@ -126,7 +127,7 @@ def main():
         first = (s * world + rank) * B                   # global frame index: results independent of N
         info = e.make_frames(seed, first, B)
         x = e.tx(info, peak=0.8)
-        e.channel_(x, args.channel, args.snr, seed, first_frame=first)
+        e.channel_exact_(x, args.channel, args.snr, seed, first_frame=first)   # the reference's own mt19937 stream: seed + frame
         batches.append(x)
         infos.append(info)
     torch.cuda.synchronize()

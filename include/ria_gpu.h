@@ -301,6 +301,13 @@ int ria_link_cap_initial_rate(float snr_db, float fading_index, int candidate_ra
  * encodes on the device). */
 int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, uint8_t* coded_out);
 
+/* The same channel with the REFERENCE's random stream: frame f is sim::WattersonChannel(cfg, seed32) with
+ * seed32 = (uint32_t)(seed + first_frame + f) (std::mt19937 + std::normal_distribution<float>, five draws per
+ * sample), so the output is bit-identical to the reference channel (and to tools/test_waveform_simple.cpp's
+ * "channel seed = base + frame" convention).  Any frame length; frame f at samples_dev + f*stride; in place. */
+int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32_t seed, uint64_t first_frame,
+                                float* samples_dev, int64_t stride, int frame_samples, int n_frames, void* stream);
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

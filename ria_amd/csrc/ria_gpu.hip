@@ -729,6 +729,17 @@ int ria_gpu_channel_batch(ria_gpu_handle h, int kind, float snr_db, uint64_t see
     return RIA_OK;
 }
 
+int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32_t seed, uint64_t first_frame,
+                                float* samples_dev, int64_t stride, int frame_samples, int n_frames, void* stream) {
+    if (!h || n_frames < 0 || kind < 0 || kind > 4 || frame_samples < 0 || stride < frame_samples)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_batch: bad argument");
+    if (n_frames == 0 || frame_samples == 0) return RIA_OK;
+    if (!samples_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_batch: null samples");
+    launch_channel_exact(kind, snr_db, seed, first_frame, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream));
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ debug
 __global__ void debug_math_kernel(int op, const float* a, const float* b, int n, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -430,4 +430,149 @@ inline void launch_channel(int kind, float snr_db, uint64_t seed, uint64_t first
                        seed, first_frame, samples, frame_samples);
 }
 
+// ---------------------------------------------------------------- channel, reference-identical
+// sim::WattersonChannel::process with the reference's own random stream (hf_channel.hpp:107-177, :267-284):
+// std::mt19937(seed) -> std::normal_distribution<float> (libstdc++ Marsaglia polar, pairs), five draws per
+// sample in the order imag/real of tap 1, imag/real of tap 2, AWGN.  One wavefront per frame:
+//   * the normal stream is produced a twist (312 candidate pairs) at a time by all lanes, acceptance ranked
+//     with ballot prefix counts so that the accepted values land in draw order (as normal648_wave does);
+//   * the four fading recurrences f = (1-a) f + a n are independent serial chains: lanes 0..3 walk a tile;
+//   * mixing, the delayed tap and the AWGN add are one lane per sample; the signal power that scales the
+//     noise is a left-to-right sum over the frame (lane 0).
+// Output is bit-identical to the reference channel for the same (preset, SNR, seed).
+constexpr int kChanTile = 512, kChanNbuf = 5 * kChanTile + 704;
+struct ChanExactArgs {
+    float* samples; long long stride; int frame_samples; int n_frames;
+    int fading, multipath, delay;
+    float alpha, one_minus_alpha, ns, g1, g2, noise_gain;
+    uint32_t seed; uint64_t first_frame;
+};
+__host__ __device__ inline int chan_exact_lds_bytes() { return 624 * 4 + kChanNbuf * 4 + 4 * kChanTile * 4 + kChanTile * 4 + 128 * 4 + 256 * 4 + 64; }
+
+__global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* st = reinterpret_cast<uint32_t*>(smem);
+    float* nbuf = reinterpret_cast<float*>(st + 624);
+    float* fr = nbuf + kChanNbuf;              // [4][tile]
+    float* xt = fr + 4 * kChanTile;            // original samples of the tile
+    float* hist = xt + kChanTile;              // last delay+1 original samples of the previous tile
+    float* tmp = hist + 128;                   // [256]
+    const int lane = threadIdx.x, n = A.frame_samples;
+    float* x = A.samples + static_cast<long long>(blockIdx.x) * A.stride;
+    // signal power over the non-zero samples (left-to-right), noise sigma
+    float power = 0.0f; int cnt = 0;
+    for (int base = 0; base < n; base += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = base + 64 * q + lane; tmp[64 * q + lane] = (i < n) ? x[i] : 0.0f; }
+        wave_sync();
+        if (lane == 0) {
+            const int m = (n - base < 256) ? n - base : 256;
+            for (int i = 0; i < m; ++i) { const float v = tmp[i]; if (fabs_(v) > 1e-6f) { power += v * v; cnt++; } }
+        }
+        wave_sync();
+    }
+    power = __shfl(power, 0); cnt = __shfl(cnt, 0);
+    const float rms = cnt ? fsqrt(fdiv(power, static_cast<float>(cnt))) : 0.1f;
+    const float nstd = rms * A.noise_gain;
+    mt_seed_wave(st, A.seed + static_cast<uint32_t>(A.first_frame + blockIdx.x), lane);
+    for (int i = lane; i < 128; i += 64) hist[i] = 0.0f;
+    int have = 0;
+    const int per = A.fading ? 5 : 1;
+    float fc = (lane == 0 || lane == 2) ? 1.0f : 0.0f;       // lanes 0..3: f1.re, f1.im, f2.re, f2.im
+    const int pick = (lane == 0) ? 1 : (lane == 1) ? 0 : (lane == 2) ? 3 : 2;   // imag is drawn before real
+    for (int base = 0; base < n; base += kChanTile) {
+        const int tn = (n - base < kChanTile) ? n - base : kChanTile;
+        const int need = per * tn;
+        while (have < need) {
+            mt_twist_wave(st, lane);
+            for (int pb = 0; pb < 312; pb += 64) {
+                const int p = pb + lane;
+                bool acc = false;
+                float u = 0.f, v = 0.f, r2 = 1.f;
+                if (p < 312) {
+                    u = 2.0f * mt_canonical(st[2 * p]) - 1.0f;
+                    v = 2.0f * mt_canonical(st[2 * p + 1]) - 1.0f;
+                    r2 = u * u + v * v;
+                    acc = !(r2 > 1.0f || r2 == 0.0f);
+                }
+                const unsigned long long mask = __ballot(acc);
+                if (acc) {
+                    const int q = have + 2 * __popcll(mask & ((1ull << lane) - 1ull));
+                    const float mult = fsqrt(fdiv(-2.0f * logf_glibc(r2), r2));
+                    nbuf[q] = v * mult;          // returned first
+                    nbuf[q + 1] = u * mult;      // saved, returned by the next call
+                }
+                have += 2 * __popcll(mask);
+            }
+            wave_sync();
+        }
+        for (int i = lane; i < tn; i += 64) xt[i] = x[base + i];
+        wave_sync();
+        if (A.fading && lane < 4) {
+            for (int i = 0; i < tn; ++i) {
+                const float g = nbuf[5 * i + pick];
+                fc = A.one_minus_alpha * fc + A.alpha * (A.ns * g);
+                fr[lane * kChanTile + i] = fc;
+            }
+        }
+        wave_sync();
+        for (int i = lane; i < tn; i += 64) {
+            const float sv = xt[i];
+            float h1 = 1.0f, h2 = 1.0f;
+            if (A.fading) { h1 = hypotf_glibc(fr[i], fr[kChanTile + i]); h2 = hypotf_glibc(fr[2 * kChanTile + i], fr[3 * kChanTile + i]); }
+            float o = 0.0f;
+            if (A.multipath && A.delay > 0) {
+                o += sv * A.g1 * h1;
+                const int j = i - A.delay - 1;
+                const float delayed = (j >= 0) ? xt[j] : hist[128 + j];     // j in [-(delay+1), -1]
+                o += delayed * A.g2 * h2;
+            } else {
+                o = sv * h1;
+            }
+            o += nstd * nbuf[per * i + (per - 1)];
+            x[base + i] = o;
+        }
+        wave_sync();
+        // history for the next tile's delayed tap, leftover normals to the front
+        for (int i = lane; i < 128; i += 64) { const int j = tn - 128 + i; tmp[i] = (j >= 0) ? xt[j] : hist[(i + tn < 128) ? i + tn : 127]; }
+        wave_sync();
+        for (int i = lane; i < 128; i += 64) hist[i] = tmp[i];
+        const int left = have - need;
+        for (int b0 = 0; b0 < left; b0 += 64) {
+            const int i = b0 + lane;
+            const float t = (i < left) ? nbuf[need + i] : 0.0f;
+            wave_sync();
+            if (i < left) nbuf[i] = t;
+            wave_sync();
+        }
+        have = left;
+        wave_sync();
+    }
+}
+
+inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t first_frame, float* samples, long long stride,
+                                 int frame_samples, int n_frames, hipStream_t s) {
+    float delay_ms = 0, doppler = 0, g1 = 1.0f, g2 = 0.0f;  // presets hf_channel.hpp:411-488
+    int fading = 1, multipath = 1;
+    switch (kind) {
+        case 0: fading = 0; multipath = 0; break;
+        case 1: delay_ms = 0.5f; doppler = 0.1f; g1 = g2 = 0.707f; break;
+        case 2: delay_ms = 1.0f; doppler = 0.5f; g1 = g2 = 0.707f; break;
+        case 3: delay_ms = 2.0f; doppler = 1.0f; g1 = g2 = 0.707f; break;
+        default: delay_ms = 0.5f; doppler = 10.0f; g1 = g2 = 0.707f; break;
+    }
+    ChanExactArgs A{};
+    A.samples = samples; A.stride = stride; A.frame_samples = frame_samples; A.n_frames = n_frames;
+    A.fading = fading; A.multipath = multipath;
+    A.delay = static_cast<int>(delay_ms * 48000 / 1000.0f);
+    const float norm_dopp = doppler / 48000;
+    A.alpha = static_cast<float>(1.0f - std::exp(-2.0f * 3.14159265358979323846 * static_cast<double>(norm_dopp)));   // hf_channel.hpp:84-90
+    A.one_minus_alpha = 1.0f - A.alpha;
+    A.ns = fading ? std::sqrt(1.0f / A.alpha) : 0.0f;
+    A.g1 = g1; A.g2 = g2;
+    A.noise_gain = powf(10.0f, -snr_db / 20.0f);
+    A.seed = seed; A.first_frame = first_frame;
+    hipLaunchKernelGGL(channel_exact_kernel, dim3(n_frames), dim3(64), chan_exact_lds_bytes(), s, A);
+}
+
 }  // namespace ria

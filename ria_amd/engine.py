@@ -244,6 +244,14 @@ class RxEngine:
                                                          _ptr(stored), _stream_ptr()))
         return stored
 
+    def channel_exact_(self, samples, kind, snr_db, seed, first_frame=0):
+        """Reference-identical channel (mt19937 stream, seed + first_frame + f per frame); in place, any frame length."""
+        n, fs = samples.shape
+        assert samples.dtype == torch.float32 and samples.is_contiguous()
+        self._check(self.lib.ria_gpu_channel_exact_batch(self.h, int(kind), float(snr_db), int(seed) & 0xffffffff, int(first_frame),
+                                                         _ptr(samples), fs, fs, n, _stream_ptr()))
+        return samples
+
     def debug_math(self, op, a, b=None):
         out = torch.empty_like(a)
         self._check(self.lib.ria_gpu_debug_math(self.h, op, _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream_ptr()))

@@ -60,7 +60,7 @@ def run_point_gpu(engine, point, base_seed, point_index, start, n):
     first = point_index * (1 << 32) + start          # disjoint global frame indices per point
     info = engine.make_frames(base_seed, start, n)
     x = engine.tx(info, peak=0.8)
-    engine.channel_(x, point.channel, point.snr_db, base_seed + 7919 * (point_index + 1), first_frame=first)
+    engine.channel_exact_(x, point.channel, point.snr_db, base_seed + 7919 * (point_index + 1), first_frame=first)
     out, st = engine.rx(x)
     s = engine.decode_status(st)
     ok = s["cw_ok"].all(axis=1) & s["frame_valid"].astype(bool)

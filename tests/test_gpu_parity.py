@@ -493,6 +493,28 @@ def test_sync_and_mcdpsk_edge_cases(oracle):
     assert e.lib.ria_gpu_last_error(h) != b""
 
 
+@pytest.mark.parametrize("kind,snr", [(0, 12.0), (1, 15.0), (2, 20.0), (3, 8.0), (4, 25.0)])
+def test_channel_exact_is_bit_identical_to_reference_channel(oracle, golden, kind, snr):
+    """ria_gpu_channel_exact_batch reproduces sim::WattersonChannel's mt19937/normal_distribution stream: same
+    samples out, bit for bit (oracle = restatement pinned to the reference; fixture = the reference itself)."""
+    e = engine("QAM16", "R1_2")
+    rng = np.random.default_rng(40 + kind)
+    frames = []
+    for f in range(5):
+        s, info, coded = oracle.tx_frame(po.QAM16, po.R1_2, rng.integers(0, 256, 141, dtype=np.uint8), f)
+        frames.append(s * np.float32(0.8 / np.abs(s).max()))
+    X = np.stack(frames)
+    X[3, :700] = 0.0                                  # leading silence: excluded from the power estimate
+    y = e.channel_exact_(dev(X.copy()), kind, snr, 1000, first_frame=7).cpu().numpy()
+    for f in range(len(frames)):
+        exp = oracle.channel(kind, snr, 1000 + 7 + f, X[f])
+        assert np.array_equal(bits(y[f]), bits(exp)), f"frame {f}: first diff at {np.nonzero(bits(y[f]) != bits(exp))[0][:4]}"
+    g = golden("channel_vectors")                     # recorded from the reference: odd length, 200 leading zeros
+    x = g["x"]
+    out = e.channel_exact_(dev(x[None, :].copy()), kind, 15.0, 77 + kind).cpu().numpy()[0]
+    assert np.array_equal(bits(out), bits(g[f"y_{kind}"]))
+
+
 def test_loopback_round_trip_full_size():
     """Size-independent property at bench scale: make_frames -> tx -> AWGN 20 dB -> rx returns the
     transmitted bytes for (nearly) every frame, and frame_valid agrees with byte equality."""
