@@ -515,6 +515,31 @@ def test_channel_exact_is_bit_identical_to_reference_channel(oracle, golden, kin
     assert np.array_equal(bits(out), bits(g[f"y_{kind}"]))
 
 
+def test_bench_workload_sample_end_to_end_vs_oracle(oracle):
+    """The bench workload itself (make_frames -> TX -> reference-identical Watterson moderate 20 dB -> fused RX with
+    the full decodeFixedFrame) for a sample of frames, against the CPU chain run by the oracle on the SAME frames:
+    channel output, payload bytes, per-codeword success / iterations / attempts and frame validity all identical."""
+    e = engine("QAM16", "R1_2")
+    n, seed, first = 40, 20261004, 25000 * 3
+    info = e.make_frames(seed, first, n)
+    x = e.tx(info, peak=0.8)
+    tx_h = x.cpu().numpy().copy()
+    e.channel_exact_(x, 2, 20.0, seed, first_frame=first)
+    y = x.cpu().numpy()
+    out, st = e.rx(x)
+    out, s = out.cpu().numpy(), e.decode_status(st)
+    n_valid = 0
+    for f in range(n):
+        yo = oracle.channel(2, 20.0, (seed + first + f) & 0xffffffff, tx_h[f])
+        assert np.array_equal(bits(y[f]), bits(yo)), f"frame {f}: channel"
+        llr_o, aux = oracle.rx_process(po.QAM16, po.R1_2, yo)
+        d, ok, iters, att = oracle.decode_fixed_frame(llr_o, po.R1_2, True, 188, flags=7)
+        assert np.array_equal(s["cw_ok"][f], ok) and np.array_equal(out[f], d), f"frame {f}: decode"
+        assert np.array_equal(s["iterations"][f], iters.astype(np.uint16)) and np.array_equal(s["attempts"][f], att.astype(np.uint8))
+        n_valid += int(s["frame_valid"][f])
+    assert 10 <= n_valid <= n
+
+
 def test_loopback_round_trip_full_size():
     """Size-independent property at bench scale: make_frames -> tx -> AWGN 20 dB -> rx returns the
     transmitted bytes for (nearly) every frame, and frame_valid agrees with byte equality."""
