@@ -798,6 +798,7 @@ static void chirp_fft_forward(const ChirpArgs& A, int chunk, hipStream_t s, bool
 }
 static void chirp_fft_inverse_mag(const ChirpArgs& A, int chunk, hipStream_t s) {
     const dim3 g16(kChFft / 16 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
+    (void)hipMemsetAsync(A.best, 0, static_cast<size_t>(chunk) * sizeof(unsigned long long), s);
     hipLaunchKernelGGL((chirp_fft_pass<4, 0, 2, true>), g16, blk, 0, s, A, static_cast<const float2*>(A.w1), A.w2);
     hipLaunchKernelGGL((chirp_fft_pass<4, 4, 0, true>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
     hipLaunchKernelGGL((chirp_fft_pass<4, 8, 0, true>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
@@ -823,7 +824,7 @@ static int chirp_prepare(ria_gpu_handle h, int chunk, int outer, hipStream_t s) 
         const size_t c = static_cast<size_t>(chunk);
         C_TRY(hipMalloc(&h->d_ch_w1, c * kChFft * sizeof(float2)));
         C_TRY(hipMalloc(&h->d_ch_w2, c * kChFft * sizeof(float2)));
-        C_TRY(hipMalloc(&h->d_ch_mag, c * kChFft * sizeof(float)));
+        C_TRY(hipMalloc(&h->d_ch_mag, c * sizeof(unsigned long long)));   // packed first-maximum keys
         h->ch_chunk = chunk;
     }
     if (outer > h->ch_outer) {
@@ -872,7 +873,7 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.threshold = threshold;
     A.tw = static_cast<const float2*>(h->d_ch_tw); A.tmpl_fft = static_cast<const float2*>(h->d_ch_tmpl_fft);
     A.tmpl = static_cast<const float*>(h->d_ch_tmpl); A.tmpl_energy[0] = h->ch_energy[0]; A.tmpl_energy[1] = h->ch_energy[1];
-    A.w1 = static_cast<float2*>(h->d_ch_w1); A.w2 = static_cast<float2*>(h->d_ch_w2); A.mag = static_cast<float*>(h->d_ch_mag);
+    A.w1 = static_cast<float2*>(h->d_ch_w1); A.w2 = static_cast<float2*>(h->d_ch_w2); A.best = static_cast<unsigned long long*>(h->d_ch_mag);
     A.cum = static_cast<float*>(h->d_ch_cum); A.st = static_cast<ChirpBufState*>(h->d_ch_st); A.out = out_dev;
     for (int first = 0; first < n_buffers; first += outer) {
         const int nb = std::min(outer, n_buffers - first);
@@ -886,7 +887,7 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
                 A.sub = sub; A.n_sub = std::min(chunk, nb - sub);
                 chirp_fft_forward(A, A.n_sub, s, true, true);
                 chirp_fft_inverse_mag(A, A.n_sub, s);
-                hipLaunchKernelGGL(chirp_peak_kernel, dim3(A.n_sub), dim3(256), 0, s, A);
+                hipLaunchKernelGGL(chirp_peak_kernel, dim3((A.n_sub + 63) / 64), dim3(64), 0, s, A);
             }
         }
         A.sub = 0; A.n_sub = nb;

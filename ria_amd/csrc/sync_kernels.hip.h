@@ -241,7 +241,8 @@ struct ChirpArgs {
     const float* tmpl;         // [4][24000] up sin, up cos, down sin, down cos
     float tmpl_energy[2];
     float2* w1; float2* w2;    // [chunk][131072]
-    float* mag;                // [chunk][131072]
+    float* mag;                // [chunk][131072] (unused since the peak search moved into the last inverse pass)
+    unsigned long long* best;  // [chunk] packed (normalised correlation bits << 32) | ~position: atomicMax = first maximum
     float* cum;                // [outer chunk][131073]
     ChirpBufState* st;         // [outer chunk]
     ria_chirp_result* out;     // [all buffers]
@@ -409,45 +410,52 @@ __global__ __launch_bounds__(256) void chirp_fft_pass(ChirpArgs A, const float2*
 #pragma unroll
         for (int j = 0; j < R; ++j) { const int i = idx0 + j * stridej; dst[i] = ch_cmul(x[j], tf[i]); }
     } else if constexpr (MODE == 4) {
-        float* mag = A.mag + static_cast<size_t>(b) * kChFft;
+        // scale by 1/N, |.|, normalise by the sliding energy and keep the FIRST maximum over pos < search_len
+        // (chirp_sync.hpp:677-693): larger value wins, equal values -> smaller position, which is exactly an
+        // unsigned max of (value bits, ~position) because the values are non-negative floats
+        const float* cum = A.cum + static_cast<size_t>(A.sub + b) * (kChFft + 1);
+        const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
+        const int search_len = fft_in - kChLen;
+        const float te = A.tmpl_energy[A.down];
         const float scale = 1.0f / static_cast<float>(kChFft);
+        unsigned long long key = 0ull;
 #pragma unroll
-        for (int j = 0; j < R; ++j) mag[idx0 + j * stridej] = hypotf_glibc(x[j].x * scale, x[j].y * scale);
+        for (int j = 0; j < R; ++j) {
+            const int pos = idx0 + j * stridej;
+            if (pos < search_len) {
+                const float mag = hypotf_glibc(x[j].x * scale, x[j].y * scale);
+                const float se = cum[pos + kChLen] - cum[pos];
+                const float denom = fsqrt(se * te);
+                const float nc = (denom > 1e-10f) ? fdiv(mag, denom) : 0.0f;
+                if (nc > 0.0f) {
+                    const unsigned long long k = (static_cast<unsigned long long>(f2u(nc)) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(pos));
+                    key = k > key ? k : key;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off);
+            key = o > key ? o : key;
+        }
+        if ((threadIdx.x & 63) == 0 && key) atomicMax(A.best + b, key);
     } else {
 #pragma unroll
         for (int j = 0; j < R; ++j) dst[idx0 + j * stridej] = x[j];
     }
 }
 
-// first maximum of |corr[pos]| / sqrt(sig_energy * tmpl_energy) over pos < search_len (:677-693)
-__global__ __launch_bounds__(256) void chirp_peak_kernel(ChirpArgs A) {
-    __shared__ float sv[4]; __shared__ int si[4];
-    const int b = blockIdx.x;                       // workspace slot
+// unpack the first maximum found by the last inverse pass, apply the threshold (:707-711)
+__global__ void chirp_peak_kernel(ChirpArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.n_sub) return;
     ChirpBufState& s = A.st[A.sub + b];
     if (s.active != 1) return;
-    const float* mag = A.mag + static_cast<size_t>(b) * kChFft;
-    const float* cum = A.cum + static_cast<size_t>(A.sub + b) * (kChFft + 1);
-    const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
-    const int search_len = fft_in - kChLen;
-    const float te = A.tmpl_energy[A.down];
-    float best = 0.0f; int bp = -1;
-    for (int pos = threadIdx.x; pos < search_len; pos += 256) {
-        const float se = cum[pos + kChLen] - cum[pos];
-        const float denom = fsqrt(se * te);
-        const float nc = (denom > 1e-10f) ? fdiv(mag[pos], denom) : 0.0f;
-        if (nc > best) { best = nc; bp = pos; }     // ascending pos within the thread: first maximum kept
-    }
-    float v = (bp >= 0) ? best : -1.0f; int idx = bp;
-    wave_argmax_first(v, idx);
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float bv = -1.0f; int bi = -1;
-        for (int w = 0; w < 4; ++w) if (sv[w] > bv || (sv[w] == bv && si[w] >= 0 && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-        const float corr = (bi >= 0) ? bv : 0.0f;
-        s.corr = corr;
-        s.pos = (bi >= 0 && !(corr < A.threshold)) ? bi : -1;
-    }
+    const unsigned long long key = A.best[b];
+    const float corr = key ? u2f(static_cast<uint32_t>(key >> 32)) : 0.0f;
+    const int pos = key ? static_cast<int>(0xFFFFFFFFu - static_cast<uint32_t>(key & 0xFFFFFFFFull)) : -1;
+    s.corr = corr;
+    s.pos = (pos >= 0 && !(corr < A.threshold)) ? pos : -1;
 }
 
 // time-domain path of detectChirpTemplate (:759-817) for short windows: one workgroup per buffer,
