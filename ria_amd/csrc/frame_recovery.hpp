@@ -1,10 +1,10 @@
-// ria_amd/csrc/frame_recovery.hpp — host half of v2::decodeFixedFrame: frame reassembly, CRC
-// verification and the "LDPC false positive" recovery (src/protocol/frame_v2.cpp:1564-1880).
+// ria_amd/csrc/frame_recovery.hpp — HOST restatement of the frame reassembly, CRC verification and "LDPC false
+// positive" recovery of v2::decodeFixedFrame (src/protocol/frame_v2.cpp:1564-1880).
 //
-// This is byte-level control logic that touches ~1 % of frames (all four codewords converged but the
-// frame CRC fails), so it stays on the host like the rest of src/protocol; the LDPC re-decodes it
-// needs are done on the GPU beforehand (16 per flagged frame, batched) and passed in.
-// Product code, independent of oracle/.
+// The product path runs these searches on the GPU (recovery_kernels.hip.h).  This host version is selected
+// with RIA_RECOVERY_HOST=1 and exists so that the tests can run both implementations on the same frames and
+// compare them (tests/test_gpu_parity.py::test_crc_recovery_device_vs_host_vs_oracle); the LDPC re-decodes it
+// needs are still done on the GPU beforehand and passed in.  Product code, independent of oracle/.
 #pragma once
 #include <algorithm>
 #include <atomic>

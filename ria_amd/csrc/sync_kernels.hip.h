@@ -476,7 +476,7 @@ __device__ inline float chirp_td_corr(const float* x, int n, int offset, const f
     return fdiv(fsqrt(ci * ci + cq * cq), denom);
 }
 __global__ __launch_bounds__(256) void chirp_td_kernel(ChirpArgs A) {
-    __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sbest; __shared__ int spos;
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int spos;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     ChirpBufState& s = A.st[b];
     if (s.active != 2) return;
@@ -538,7 +538,6 @@ __global__ __launch_bounds__(256) void chirp_td_kernel(ChirpArgs A) {
         pos_out = (best >= A.threshold) ? best_pos : -1;
     }
     if (tid == 0) { s.corr = best; s.pos = pos_out; }
-    (void)sbest;
 }
 
 // CFO and position correction from the two detections (:454-509)

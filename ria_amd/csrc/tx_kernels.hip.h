@@ -6,9 +6,10 @@
 //                       OFDMModulator::generateTrainingSymbols/modulate  modulator.cpp:534-583, :348-477
 //                       createOFDMSymbol/complexToReal (IFFT, CP, upmix x40) modulator.cpp:217-283
 //                       -> bit-identical audio to the reference TX for the same info bytes
-//   channel_kernel      sim::WattersonChannel::process                   hf_channel.hpp:107-177, :267-284
-//                       counter-based RNG (Philox4x32-10), so only STATISTICAL parity with the
-//                       reference's sequential mt19937 stream (SURVEY.md §7 hard part 5)
+//   channel_exact_kernel  sim::WattersonChannel::process                 hf_channel.hpp:107-177, :267-284
+//                       the reference's own mt19937 -> normal_distribution<float> stream: bit-identical output
+//   channel_kernel      the same model on a counter-based RNG (Philox4x32-10): order-independent and faster,
+//                       STATISTICAL parity only
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
