@@ -57,6 +57,8 @@ struct ria_gpu {
     CoreTables ftab;
     void* d_f_row_addr = nullptr; void* d_f_col_addr = nullptr; void* d_f_check_at = nullptr; void* d_f_col_at = nullptr; void* d_f_col_pos = nullptr;
     int wave_lds = 0;
+    hipStream_t aux_stream[2] = {nullptr, nullptr};   // ria_gpu_rx_batch: the two halves of a large batch overlap here
+    hipEvent_t aux_event[3] = {nullptr, nullptr, nullptr};
     DecodeCtl* d_ctl = nullptr;           // cascade work-list control block
     unsigned int* d_entries = nullptr;    // [4 * ws_frames]
     unsigned int* d_best = nullptr;       // [4 * ws_frames]
@@ -143,7 +145,7 @@ static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
         if (p_) (void)hipFree(p_);
     h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr;
     hipError_t e;
-    if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), sizeof(DecodeCtl))) != hipSuccess) return e;
+    if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), 2 * sizeof(DecodeCtl))) != hipSuccess) return e;   // one per stream slot
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_entries), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_best), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_list1), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
@@ -182,7 +184,7 @@ static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames, bool host_s
 #define A_TRY(expr) if ((e = (expr)) != hipSuccess) return e
     if (n_frames > h->rec_frames) {
         for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_stage2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16));
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 32));   // one 16-byte counter block per stream slot
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_stage2), n * 4));
@@ -233,18 +235,20 @@ __global__ void recovery_scatter_kernel(int nf, const unsigned int* __restrict__
 // synchronises.  RIA_RECOVERY_HOST=1 selects the host restatement of the same searches
 // (frame_recovery.hpp) instead, which the tests use to cross-check the two implementations.
 static int run_crc_recovery_host(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s);
-static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s) {
+static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream_t s, int slot = 0, int ws_off = 0) {
     const char* env = getenv("RIA_RECOVERY_HOST");   // read per call: tests flip it
     const bool on_host = env != nullptr && env[0] == '1';
     if (on_host) return run_crc_recovery_host(h, D, s);
     const int n_frames = D.n_frames;
-    hipError_t e0 = ensure_recovery_ws(h, std::max(n_frames, h->cfg.max_batch), false);
+    hipError_t e0 = ensure_recovery_ws(h, std::max(ws_off + n_frames, h->cfg.max_batch), false);
     if (e0 != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery workspace: %s", hipGetErrorString(e0));
     RecoveryArgs R{};
     R.d = D;
-    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1; R.n_stage2 = h->d_rctl + 2;
-    R.flagged = h->d_flagged; R.list2 = h->d_list2; R.stage2 = h->d_stage2; R.list_units_now = 0;
-    if (hipMemsetAsync(h->d_rctl, 0, 16, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
+    unsigned int* rctl = h->d_rctl + 4 * slot;
+    R.n_flagged = rctl; R.n_list2 = rctl + 1; R.n_stage2 = rctl + 2;
+    R.flagged = h->d_flagged + ws_off; R.list2 = h->d_list2 + static_cast<size_t>(ws_off) * 16; R.stage2 = h->d_stage2 + ws_off;
+    R.list_units_now = 0;
+    if (hipMemsetAsync(rctl, 0, 16, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
     const int rl = recovery_lds_bytes(h->geo.bytes_per_codeword);
     hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
     hipLaunchKernelGGL(recovery_stage1_kernel, dim3(n_frames), dim3(64), rl, s, R);
@@ -362,6 +366,8 @@ void ria_gpu_destroy(ria_gpu_handle h) {
                     h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& st_ : h->aux_stream) if (st_) (void)hipStreamDestroy(st_);
+    for (auto& ev_ : h->aux_event) if (ev_) (void)hipEventDestroy(ev_);
     for (auto& kv : h->d_mc_mixer) if (kv.second) (void)hipFree(kv.second);
     if (h->d_mc_hilbert) (void)hipFree(h->d_mc_hilbert);
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
@@ -510,12 +516,15 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
     return RIA_OK;
 }
 
+// slot / ws_off: which control block and which frame range of the per-handle workspace this launch owns
+// (ria_gpu_rx_batch runs the two halves of a large batch on two streams: slot 0 at offset 0, slot 1 behind it)
 static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride, int n_frames, uint32_t flags,
-                         uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s) {
-    hipError_t e = ensure_decode_ws(h, n_frames);
+                         uint8_t* info_out_dev, ria_decode_status* status_dev, hipStream_t s, int slot = 0, int ws_off = 0) {
+    hipError_t e = ensure_decode_ws(h, ws_off + n_frames);
     if (e != hipSuccess) return fail(h, RIA_ERR_HIP, "decode workspace: %s", hipGetErrorString(e));
     FastDecodeArgs A;
-    if ((e = hipMemsetAsync(h->d_res, 0, static_cast<size_t>(n_frames) * 4 * sizeof(CwResult), s)) != hipSuccess)
+    const size_t o4 = static_cast<size_t>(ws_off) * 4;
+    if ((e = hipMemsetAsync(h->d_res + o4, 0, static_cast<size_t>(n_frames) * 4 * sizeof(CwResult), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     A.c = h->fast;
     A.gather = static_cast<const uint16_t*>((flags & RIA_DECODE_NO_CHANNEL_DEINTERLEAVE) ? h->d_gather_nochan : h->d_gather);
@@ -527,13 +536,13 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.status = status_dev;
     A.crc_bit = static_cast<const uint16_t*>(h->d_crc_bit);
     A.crc_init = static_cast<const uint16_t*>(h->d_crc_init);
-    A.ctl = h->d_ctl;
-    A.entries = h->d_entries;
-    A.best = h->d_best;
-    A.list1 = h->d_list1;
-    A.res = h->d_res;
-    A.res_bytes = h->d_res_bytes;
-    if ((e = hipMemsetAsync(h->d_ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
+    A.ctl = h->d_ctl + slot;
+    A.entries = h->d_entries + o4;
+    A.best = h->d_best + o4;
+    A.list1 = h->d_list1 + o4;
+    A.res = h->d_res + o4;
+    A.res_bytes = h->d_res_bytes + o4 * kNumFactors * h->geo.bytes_per_codeword;
+    if ((e = hipMemsetAsync(A.ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const int wb = h->wave_lds;
     static const bool dbg = getenv("RIA_DEBUG_SYNC") != nullptr;   // stage-by-stage sync + trace on stderr
@@ -566,7 +575,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
                        h->geo.bytes_per_codeword, n_frames, A.crc_bit, A.crc_init, status_dev);
     stage("validate");
     if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "decode kernel launch failed");
-    if (flags & RIA_DECODE_CRC_RECOVER) return run_crc_recovery(h, A, s);
+    if (flags & RIA_DECODE_CRC_RECOVER) return run_crc_recovery(h, A, s, slot, ws_off);
     return RIA_OK;
 }
 
@@ -614,19 +623,50 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
         return fail(h, RIA_ERR_INVALID, "ria_gpu_rx_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // Two launches on one stream: demodulate (LLRs stay in the HBM workspace / L2), then decode.
+    // Demodulate (LLRs stay in the HBM workspace / L2), then decode.  A large chunk is cut in two halves that run
+    // on two internal streams: the low-occupancy phases of one half (first decodes, phase 0, finalise, CRC
+    // recovery: 55-65 % VALU busy) overlap with the cascade of the other.  Results do not depend on the split.
+    const char* rh = getenv("RIA_RECOVERY_HOST");
+    const bool no_split = getenv("RIA_NO_SPLIT") != nullptr || (rh && rh[0] == '1') || getenv("RIA_DEBUG_SYNC") != nullptr;
     for (int done = 0; done < n_frames;) {
         int nb = n_frames - done;
         if (!llr_out_dev && nb > h->cfg.max_batch) nb = h->cfg.max_batch;
         float* llr = llr_out_dev ? llr_out_dev + static_cast<size_t>(done) * h->geo.llrs_per_frame : h->d_llr_ws;
-        const uint64_t* offs = frame_offsets_dev ? frame_offsets_dev + done : nullptr;
-        const float* smp = frame_offsets_dev ? samples_dev : samples_dev + static_cast<size_t>(done) * h->geo.frame_samples;
-        int rc = ria_gpu_demod_batch(h, smp, offs, meta_dev ? meta_dev + done : nullptr, nb, llr,
-                                     demod_status_dev ? demod_status_dev + done : nullptr, stream);
-        if (rc != RIA_OK) return rc;
-        rc = launch_decode(h, llr, h->geo.llrs_per_frame, nb, flags,
-                           info_out_dev + static_cast<size_t>(done) * h->geo.info_bytes_per_frame, decode_status_dev + done, s);
-        if (rc != RIA_OK) return rc;
+        const int n_parts = (!no_split && nb >= 4096) ? 2 : 1;
+        {   // grow the workspaces BEFORE anything is in flight: the two halves share them
+            hipError_t e = ensure_decode_ws(h, nb);
+            if (e == hipSuccess && (flags & RIA_DECODE_CRC_RECOVER)) e = ensure_recovery_ws(h, std::max(nb, h->cfg.max_batch), false);
+            if (e != hipSuccess) return fail(h, RIA_ERR_HIP, "rx workspace: %s", hipGetErrorString(e));
+        }
+        if (n_parts == 2 && !h->aux_stream[0]) {
+            for (auto& st_ : h->aux_stream) HIP_TRY(h, hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+            for (auto& ev_ : h->aux_event) HIP_TRY(h, hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+        }
+        if (n_parts == 2) {
+            HIP_TRY(h, hipEventRecord(h->aux_event[0], s));
+            for (auto& st_ : h->aux_stream) HIP_TRY(h, hipStreamWaitEvent(st_, h->aux_event[0], 0));
+        }
+        const int half = (n_parts == 2) ? ((nb / 2 + 7) & ~7) : nb;
+        for (int part = 0; part < n_parts; ++part) {
+            const int p0 = part * half, pn = (part == 0) ? half : nb - half;
+            hipStream_t ps = (n_parts == 2) ? h->aux_stream[part] : s;
+            const int g0 = done + p0;
+            const uint64_t* offs = frame_offsets_dev ? frame_offsets_dev + g0 : nullptr;
+            const float* smp = frame_offsets_dev ? samples_dev : samples_dev + static_cast<size_t>(g0) * h->geo.frame_samples;
+            float* pl = llr + static_cast<size_t>(p0) * h->geo.llrs_per_frame;
+            int rc = ria_gpu_demod_batch(h, smp, offs, meta_dev ? meta_dev + g0 : nullptr, pn, pl,
+                                         demod_status_dev ? demod_status_dev + g0 : nullptr, ps);
+            if (rc != RIA_OK) return rc;
+            rc = launch_decode(h, pl, h->geo.llrs_per_frame, pn, flags, info_out_dev + static_cast<size_t>(g0) * h->geo.info_bytes_per_frame,
+                               decode_status_dev + g0, ps, part, p0);
+            if (rc != RIA_OK) return rc;
+        }
+        if (n_parts == 2) {
+            for (int part = 0; part < 2; ++part) {
+                HIP_TRY(h, hipEventRecord(h->aux_event[1 + part], h->aux_stream[part]));
+                HIP_TRY(h, hipStreamWaitEvent(s, h->aux_event[1 + part], 0));
+            }
+        }
         done += nb;
     }
     return RIA_OK;
