@@ -30,6 +30,7 @@
 
 using namespace ria;
 
+constexpr int kMaxParts = 4;   // ria_gpu_rx_batch overlaps up to this many parts of a batch on internal streams
 struct ria_gpu {
     ria_gpu_config cfg{};
     ria_gpu_geometry geo{};
@@ -57,8 +58,8 @@ struct ria_gpu {
     CoreTables ftab;
     void* d_f_row_addr = nullptr; void* d_f_col_addr = nullptr; void* d_f_check_at = nullptr; void* d_f_col_at = nullptr; void* d_f_col_pos = nullptr;
     int wave_lds = 0;
-    hipStream_t aux_stream[2] = {nullptr, nullptr};   // ria_gpu_rx_batch: the two halves of a large batch overlap here
-    hipEvent_t aux_event[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // ria_gpu_rx_batch: the parts of a large batch overlap here
+    hipEvent_t aux_event[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DecodeCtl* d_ctl = nullptr;           // cascade work-list control block
     unsigned int* d_entries = nullptr;    // [4 * ws_frames]
     unsigned int* d_best = nullptr;       // [4 * ws_frames]
@@ -145,7 +146,7 @@ static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
         if (p_) (void)hipFree(p_);
     h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr;
     hipError_t e;
-    if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), 2 * sizeof(DecodeCtl))) != hipSuccess) return e;   // one per stream slot
+    if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), kMaxParts * sizeof(DecodeCtl))) != hipSuccess) return e;   // one per stream slot
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_entries), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_best), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_list1), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
@@ -184,7 +185,7 @@ static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames, bool host_s
 #define A_TRY(expr) if ((e = (expr)) != hipSuccess) return e
     if (n_frames > h->rec_frames) {
         for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_stage2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 32));   // one 16-byte counter block per stream slot
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16 * kMaxParts));   // one 16-byte counter block per stream slot
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_stage2), n * 4));
@@ -632,24 +633,26 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
         int nb = n_frames - done;
         if (!llr_out_dev && nb > h->cfg.max_batch) nb = h->cfg.max_batch;
         float* llr = llr_out_dev ? llr_out_dev + static_cast<size_t>(done) * h->geo.llrs_per_frame : h->d_llr_ws;
-        const int n_parts = (!no_split && nb >= 4096) ? 2 : 1;
-        {   // grow the workspaces BEFORE anything is in flight: the two halves share them
+        static const int want_parts = getenv("RIA_SPLIT_PARTS") ? std::max(1, std::min(kMaxParts, atoi(getenv("RIA_SPLIT_PARTS")))) : 2;
+        const int n_parts = (!no_split && nb >= 4096) ? want_parts : 1;
+        {   // grow the workspaces BEFORE anything is in flight: the parts share them
             hipError_t e = ensure_decode_ws(h, nb);
             if (e == hipSuccess && (flags & RIA_DECODE_CRC_RECOVER)) e = ensure_recovery_ws(h, std::max(nb, h->cfg.max_batch), false);
             if (e != hipSuccess) return fail(h, RIA_ERR_HIP, "rx workspace: %s", hipGetErrorString(e));
         }
-        if (n_parts == 2 && !h->aux_stream[0]) {
+        if (n_parts > 1 && !h->aux_stream[0]) {
             for (auto& st_ : h->aux_stream) HIP_TRY(h, hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
             for (auto& ev_ : h->aux_event) HIP_TRY(h, hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
         }
-        if (n_parts == 2) {
+        if (n_parts > 1) {
             HIP_TRY(h, hipEventRecord(h->aux_event[0], s));
-            for (auto& st_ : h->aux_stream) HIP_TRY(h, hipStreamWaitEvent(st_, h->aux_event[0], 0));
+            for (int part = 0; part < n_parts; ++part) HIP_TRY(h, hipStreamWaitEvent(h->aux_stream[part], h->aux_event[0], 0));
         }
-        const int half = (n_parts == 2) ? ((nb / 2 + 7) & ~7) : nb;
+        const int share = (n_parts > 1) ? (((nb + n_parts - 1) / n_parts + 7) & ~7) : nb;
         for (int part = 0; part < n_parts; ++part) {
-            const int p0 = part * half, pn = (part == 0) ? half : nb - half;
-            hipStream_t ps = (n_parts == 2) ? h->aux_stream[part] : s;
+            const int p0 = part * share, pn = std::min(share, nb - p0);
+            if (pn <= 0) break;
+            hipStream_t ps = (n_parts > 1) ? h->aux_stream[part] : s;
             const int g0 = done + p0;
             const uint64_t* offs = frame_offsets_dev ? frame_offsets_dev + g0 : nullptr;
             const float* smp = frame_offsets_dev ? samples_dev : samples_dev + static_cast<size_t>(g0) * h->geo.frame_samples;
@@ -661,8 +664,8 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
                                decode_status_dev + g0, ps, part, p0);
             if (rc != RIA_OK) return rc;
         }
-        if (n_parts == 2) {
-            for (int part = 0; part < 2; ++part) {
+        if (n_parts > 1) {
+            for (int part = 0; part < n_parts; ++part) {
                 HIP_TRY(h, hipEventRecord(h->aux_event[1 + part], h->aux_stream[part]));
                 HIP_TRY(h, hipStreamWaitEvent(s, h->aux_event[1 + part], 0));
             }
