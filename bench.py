@@ -196,11 +196,11 @@ def main():
                      "fast_finalize_kernel", "frame_validate_kernel"] if t_decode >= t_demod else ["demod_frames_kernel"]
             traffic = int(sum(v["hbm_bytes_per_launch"] for k, v in tr.items() if any(n in k for n in stage)))
             pmc_note = "profiles/r01f_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r01e_sq_utilisation_pmc.json")))
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r01h_sq_utilisation_pmc.json")))
         c = sq.get("ria::fast_cascade_kernel<ria::ShapeR12>")
         if c:
             valu = {"kernel": "fast_cascade_kernel", "valu_busy_frac": c["valu_busy_frac"], "lds_busy_frac": c["lds_busy_frac"],
-                    "source": "profiles/r01e_sq_utilisation_pmc.json"}
+                    "source": "profiles/r01h_sq_utilisation_pmc.json"}
     except (OSError, ValueError, KeyError):
         pass
 
