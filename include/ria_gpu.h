@@ -308,6 +308,16 @@ int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, ui
 int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32_t seed, uint64_t first_frame,
                                 float* samples_dev, int64_t stride, int frame_samples, int n_frames, void* stream);
 
+/* ---- burst interleaver (fec::BurstInterleaver, src/fec/burst_interleaver.cpp:8-78) -----------------
+ * A burst of N physical frames carries N logical frames byte-interleaved: physical[(N*b+f)/324][(N*b+f)%324] =
+ * logical[f][b].  deinterleave works on the soft bits (8 per byte) of n_groups bursts of N frames each:
+ * frame j of group g at llr_dev + (g*N + j)*llr_stride (first 2592 used), same layout out.  interleave is the
+ * TX side on coded bytes (324 per frame).  N < 2 copies. */
+int ria_gpu_burst_deinterleave_batch(ria_gpu_handle h, const float* physical_llr_dev, int llr_stride, int burst_frames,
+                                     int n_groups, float* logical_llr_out_dev, void* stream);
+int ria_gpu_burst_interleave_batch(ria_gpu_handle h, const uint8_t* logical_bytes_dev, int burst_frames, int n_groups,
+                                   uint8_t* physical_bytes_out_dev, void* stream);
+
 /* ---- debug / test hooks ----------------------------------------------------------------------- */
 /* op: 0 sinf 1 cosf 2 logf 3 atan2f(a,b) 4 hypotf(a,b) 5 a/b 6 sqrtf(a); evaluates the device
  * math the kernels use on n arguments (tests compare against the host libm). */

@@ -38,6 +38,7 @@
 #include "ultra/logging.hpp"
 #include "ultra/types.hpp"
 #include "fec/frame_interleaver.hpp"
+#include "fec/burst_interleaver.hpp"
 #include "fec/ldpc_codec.hpp"
 #include "protocol/frame_v2.hpp"
 #include "sim/hf_channel.hpp"
@@ -376,6 +377,22 @@ void ref_link_data_mode(float snr, int waveform, float fading, float* out4) {
 int ref_link_ofdm_code_rate(float snr, float fading) { return static_cast<int>(protocol::selectOFDMCodeRate(snr, fading)); }
 int ref_link_cap_initial_rate(float snr, float fading, int cand) {
     return static_cast<int>(protocol::capInitialOFDMRate(snr, fading, static_cast<CodeRate>(cand)));
+}
+
+// fec::BurstInterleaver (src/fec/burst_interleaver.cpp:8-78): N physical frames of 324 bytes / 2592 soft bits
+int ref_burst_interleave(int n_frames, const uint8_t* logical, uint8_t* physical) {
+    std::vector<std::vector<uint8_t>> in(n_frames, std::vector<uint8_t>(324));
+    for (int f = 0; f < n_frames; ++f) std::memcpy(in[f].data(), logical + f * 324, 324);
+    auto out = fec::BurstInterleaver::interleave(in);
+    for (int f = 0; f < n_frames; ++f) std::memcpy(physical + f * 324, out[f].data(), 324);
+    return 0;
+}
+int ref_burst_deinterleave(int n_frames, const float* physical, float* logical) {
+    std::vector<std::vector<float>> in(n_frames, std::vector<float>(2592));
+    for (int f = 0; f < n_frames; ++f) std::memcpy(in[f].data(), physical + f * 2592, 2592 * sizeof(float));
+    auto out = fec::BurstInterleaver::deinterleave(in);
+    for (int f = 0; f < n_frames; ++f) std::memcpy(logical + f * 2592, out[f].data(), 2592 * sizeof(float));
+    return 0;
 }
 
 }  // extern "C"

@@ -298,4 +298,27 @@ __global__ __launch_bounds__(256) void chase_combine_kernel(float* __restrict__ 
     }
 }
 
+// fec::BurstInterleaver (src/fec/burst_interleaver.cpp:8-78): pure permutations, one thread per byte position
+__global__ __launch_bounds__(256) void burst_deinterleave_kernel(const float* __restrict__ phys, int stride, int N, int n_groups,
+                                                                 float* __restrict__ logical) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (group, frame f, byte b)
+    if (i >= n_groups * N * 324) return;
+    const int b = i % 324, f = (i / 324) % N, g = i / (324 * N);
+    int pf = f, pb = b;
+    if (N >= 2) { const int flat = N * b + f; pf = flat / 324; pb = flat % 324; }
+    const float* src = phys + static_cast<size_t>(g * N + pf) * stride + pb * 8;
+    float* dst = logical + static_cast<size_t>(g * N + f) * stride + b * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = src[k];
+}
+__global__ __launch_bounds__(256) void burst_interleave_kernel(const uint8_t* __restrict__ logical, int N, int n_groups,
+                                                               uint8_t* __restrict__ phys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_groups * N * 324) return;
+    const int b = i % 324, f = (i / 324) % N, g = i / (324 * N);
+    int pf = f, pb = b;
+    if (N >= 2) { const int flat = N * b + f; pf = flat / 324; pb = flat % 324; }
+    phys[static_cast<size_t>(g * N + pf) * 324 + pb] = logical[static_cast<size_t>(g * N + f) * 324 + b];
+}
+
 }  // namespace ria

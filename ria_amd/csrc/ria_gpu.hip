@@ -1078,6 +1078,31 @@ void ria_link_data_mode(float snr_db, int waveform, float fading_index, ria_link
 int ria_link_ofdm_code_rate(float snr_db, float fading_index) { return select_ofdm_code_rate(snr_db, fading_index); }
 int ria_link_cap_initial_rate(float snr_db, float fading_index, int candidate_rate) { return cap_initial_ofdm_rate(snr_db, fading_index, candidate_rate); }
 
+int ria_gpu_burst_deinterleave_batch(ria_gpu_handle h, const float* physical_llr_dev, int llr_stride, int burst_frames,
+                                     int n_groups, float* logical_llr_out_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_groups == 0 || burst_frames == 0) return RIA_OK;
+    if (!physical_llr_dev || !logical_llr_out_dev || physical_llr_dev == logical_llr_out_dev || llr_stride < 2592 || burst_frames < 0 || n_groups < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_burst_deinterleave_batch: bad arguments");
+    const int total = n_groups * burst_frames * 324;
+    hipLaunchKernelGGL(burst_deinterleave_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), physical_llr_dev,
+                       llr_stride, burst_frames, n_groups, logical_llr_out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+int ria_gpu_burst_interleave_batch(ria_gpu_handle h, const uint8_t* logical_bytes_dev, int burst_frames, int n_groups,
+                                   uint8_t* physical_bytes_out_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_groups == 0 || burst_frames == 0) return RIA_OK;
+    if (!logical_bytes_dev || !physical_bytes_out_dev || logical_bytes_dev == physical_bytes_out_dev || burst_frames < 0 || n_groups < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_burst_interleave_batch: bad arguments");
+    const int total = n_groups * burst_frames * 324;
+    hipLaunchKernelGGL(burst_interleave_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), logical_bytes_dev,
+                       burst_frames, n_groups, physical_bytes_out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
 int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, uint8_t* coded_out) {
     if (!h || !info || !coded_out || n_cw < 0) return RIA_ERR_INVALID;
     const LdpcCode& c = h->code;

@@ -252,6 +252,22 @@ class RxEngine:
                                                          _ptr(samples), fs, fs, n, _stream_ptr()))
         return samples
 
+    def burst_deinterleave(self, llr, burst_frames):
+        """BurstInterleaver::deinterleave: llr float32 [n_groups*N, >=2592] physical -> logical (same shape)."""
+        n, stride = llr.shape
+        assert llr.dtype == torch.float32 and llr.is_contiguous() and n % burst_frames == 0
+        out = torch.zeros_like(llr)
+        self._check(self.lib.ria_gpu_burst_deinterleave_batch(self.h, _ptr(llr), stride, burst_frames, n // burst_frames, _ptr(out), _stream_ptr()))
+        return out
+
+    def burst_interleave(self, coded, burst_frames):
+        """BurstInterleaver::interleave: coded uint8 [n_groups*N, 324] logical -> physical."""
+        n = coded.shape[0]
+        assert coded.dtype == torch.uint8 and coded.is_contiguous() and coded.shape[1] == 324 and n % burst_frames == 0
+        out = torch.zeros_like(coded)
+        self._check(self.lib.ria_gpu_burst_interleave_batch(self.h, _ptr(coded), burst_frames, n // burst_frames, _ptr(out), _stream_ptr()))
+        return out
+
     def debug_math(self, op, a, b=None):
         out = torch.empty_like(a)
         self._check(self.lib.ria_gpu_debug_math(self.h, op, _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream_ptr()))
