@@ -125,22 +125,21 @@ def run_ladder_chunk(engines, point, base_seed, point_index, start, n, max_tx=4,
     pick = torch.from_numpy(rng.integers(0, n_payloads, n)).to(dev)
     clean = torch.from_numpy(frames).to(dev)[pick]                      # [n, samples]
     info_t = torch.from_numpy(info).to(dev)[pick]
-    rms = clean.pow(2).mean(dim=1, keepdim=True).sqrt()
-    sigma = rms * (10.0 ** (-point.snr_db / 20.0))
-    gen = torch.Generator(device=dev)
-    gen.manual_seed((int(base_seed) * 1000003 + point_index * 7919 + start) & 0x7fffffffffff)
+    chan_seed = (int(base_seed) * 1000003 + point_index * 7919) & 0x7fffffff
     acc = torch.zeros((n, 648), dtype=torch.float32, device=dev)
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     decoded = torch.zeros(n, dtype=torch.uint8, device=dev)
     out = torch.zeros((n, 21), dtype=torch.uint8, device=dev)
     iters_sum, transmissions = 0, 0
-    for _ in range(max_tx):
+    for tx_no in range(max_tx):
         todo = (decoded == 0).nonzero().flatten()
         if todo.numel() == 0:
             break
         transmissions += int(todo.numel())
-        x = clean[todo] + sigma[todo] * torch.randn(clean[todo].shape, generator=gen, device=dev)
-        llr, _ = e.mcdpsk_demod(x.contiguous(), int(rec.num_carriers), bps, sp)
+        # the reference channel model on the MC-DPSK audio (any frame length): a fresh stream per (transmission, trial)
+        x = clean[todo].contiguous()
+        e.channel_exact_(x, point.channel, point.snr_db, chan_seed + 104729 * tx_no, first_frame=start + int(todo[0].item()))
+        llr, _ = e.mcdpsk_demod(x, int(rec.num_carriers), bps, sp)
         soft = llr[:, :648].contiguous()
         a, c = acc[todo].contiguous(), cnt[todo].contiguous()
         e.chase_combine(a, c, soft)                                     # first reception copies, later ones add
