@@ -574,7 +574,8 @@ def test_thousands_of_bench_frames_vs_the_reference_library():
     if not po.Ref.available():
         pytest.skip("oracle/_ref/libria_ref.so not present on this box")
     e = engine("QAM16", "R1_2")
-    n, seed, first = 2048, 20261004, 25000 * 2 + 4096
+    import os
+    n, seed, first = int(os.environ.get("RIA_BIG_SAMPLE", "2048")), 20261004, 25000 * 2 + 4096
     info = e.make_frames(seed, first, n)
     x = e.tx(info, peak=0.8)
     e.channel_exact_(x, 2, 20.0, seed, first_frame=first)
@@ -600,7 +601,7 @@ def test_thousands_of_bench_frames_vs_the_reference_library():
         for cw in range(4):
             if exp_ok[f][cw]:
                 assert np.array_equal(out[f][40 * cw:40 * cw + 40], exp_d[f][40 * cw:40 * cw + 40]), (f, cw)
-    assert 900 <= int(s["frame_valid"].sum()) <= n
+    assert 0.4 * n <= int(s["frame_valid"].sum()) <= n
 
 
 def test_loopback_round_trip_full_size():
