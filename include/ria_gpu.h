@@ -241,9 +241,35 @@ typedef struct ria_lts_result {
 int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
                            const float* known_cfo_dev, float threshold, ria_lts_result* out_dev, void* stream);
 
+/* ---- Schmidl-Cox acquisition of the OFDM-COX waveform
+ * Replaces OFDMDemodulator::searchForSync(samples, out_position, out_cfo_hz, threshold)
+ * (src/ofdm/demodulator.cpp:1450-1542) as OFDMNvisWaveform::detectSync drives it
+ * (src/waveform/ofdm_cox_waveform.cpp:125-158), for n_buffers capture buffers: energy gate with the
+ * demodulator's noise-floor tracker (ofdm_sync.cpp:20-50), half-symbol Schmidl-Cox metric on the FFT-Hilbert
+ * analytic signal (ofdm_sync.cpp:56-86,118-163) on the 64-sample search grid and the 8-sample plateau grid,
+ * plateau rule (>= 15 of 38 points at >= 0.90), passband LTS fine timing with the earlier-LTS preference and
+ * the 0.05 confirmation threshold (ofdm_sync.cpp:386-484), coarse CFO (ofdm_sync.cpp:230-261).  All fields
+ * bit-identical.  noise_floor_dev (may be NULL = fresh demodulator, 0) holds Impl::noise_floor_energy per buffer
+ * before the call; the value after the call is returned in the result.  buf_len <= 240000
+ * (MAX_BUFFER_SAMPLES). */
+typedef struct ria_cox_result {
+    int32_t found;
+    int32_t start_sample;       /* first sample of the first LTS symbol (SyncResult::start_sample) */
+    float cfo_hz;
+    float noise_floor;          /* Impl::noise_floor_energy after the search */
+    int32_t sts_position;       /* Schmidl-Cox plateau peak the LTS refinement started from */
+    int32_t reserved[3];
+} ria_cox_result;               /* 32 bytes */
+int ria_gpu_sync_cox_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                           float threshold, const float* noise_floor_dev, ria_cox_result* out_dev, void* stream);
+/* OFDMModulator::generatePreamble (src/ofdm/modulator.cpp:479-532) for the handle's configuration: one symbol
+ * of silence, 4 STS, 2 LTS = 8064 samples, bit-identical.  Returns the sample count (negative = needed). */
+int ria_gpu_cox_preamble(ria_gpu_handle h, float* out_host, int max_n);
+
 /* Single-buffer convenience forms for the IWaveform adaptor (host memory in, result by value; they stage
  * through device memory and synchronise).  kind: 0 dual chirp (ria_chirp_result), 1 LTS light sync
- * (ria_lts_result), 2 ZC (ria_zc_result); param = known CFO in Hz (kinds 1, 2), root_mask only for kind 2. */
+ * (ria_lts_result), 2 ZC (ria_zc_result), 3 Schmidl-Cox (ria_cox_result); param = known CFO in Hz (kinds 1, 2) or
+ * the initial noise floor (kind 3), root_mask only for kind 2. */
 int ria_gpu_sync_host(ria_gpu_handle h, int kind, const float* samples_host, int n_samples, float threshold, float param,
                       uint32_t root_mask, void* result_out /* 32 bytes */);
 

@@ -39,6 +39,31 @@ def zc_test_buffer(pre, buf_len, off, snr_db, cfo_hz, rng):
     return (sig + rng.normal(0, sigma, buf_len)).astype(np.float32)
 
 
+def cox_cases():
+    """(buffer length, preamble offset, snr dB, cfo Hz, threshold, initial noise floor)"""
+    return [(30000, 0, 30, 0.0, 0.8, 0.0), (30000, 5000, 20, 12.5, 0.8, 0.0), (40000, 12000, 10, -30.0, 0.8, 0.0),
+            (30000, 3000, 5, 40.0, 0.8, 0.0), (26000, 7777, 15, -8.0, 0.7, 1e-4), (50000, 30000, 25, 0.0, 0.8, 0.0),
+            (20000, 15000, 20, 0.0, 0.8, 0.0), (9215, 0, 20, 0.0, 0.8, 0.0), (3999, 0, 20, 0.0, 0.8, 0.0),
+            (30000, 4000, 0, 0.0, 0.8, 0.0), (30000, 4000, 30, 0.0, 0.95, 0.0), (30000, -1, 20, 0.0, 0.8, 0.0),
+            (9300, 100, 25, 5.0, 0.8, 0.0), (16000, 500, 25, 5.0, 0.8, 0.0), (30000, 2000, 12, 20.0, 0.5, 0.0),
+            (60000, 2000, 30, 0.0, 0.8, 0.0, 1), (60000, 6000, 22, 15.0, 0.8, 0.0, 1), (30000, 2000, 18, -20.0, 0.6, 0.0),
+            (30000, 9000, 40, 45.0, 0.8, 0.0), (24000, 64, 25, 0.0, 0.8, 0.0), (30000, 2000, 28, 0.0, 0.8, 5e-3)]
+
+
+def cox_test_buffer(R, buf_len, off, snr_db, cfo_hz, rng, variant=0):
+    """Schmidl-Cox preamble + one modulated frame of random coded bytes at `off` (off < 0: noise only).
+    variant 1: a preamble cut off after its STS part (Schmidl-Cox plateau without LTS confirmation: the search
+    must carry on), silence, then a complete transmission."""
+    coded = rng.integers(0, 256, 324, dtype=np.uint8)
+    tx = R.cox_transmit(coded)
+    if variant == 1:
+        tx = np.concatenate([tx[:5 * 1152], np.zeros(12 * 1152, np.float32), tx])
+    if off < 0:
+        rms = np.sqrt(np.mean(tx[tx != 0].astype(np.float64) ** 2))
+        return rng.normal(0, rms * 10 ** (-snr_db / 20.0), buf_len).astype(np.float32)
+    return zc_test_buffer(tx, buf_len, off, snr_db, cfo_hz, rng)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=12)
@@ -173,6 +198,21 @@ def main():
             worst = f"len={buf_len} off={off} snr={snr_db} cfo={cfo} oracle={a} ref={b}"
         n_det += int(b[0])
     check(f"chirp_detect ({n_det}/{len(cases)} detected by ref)", ok, worst)
+
+    # Schmidl-Cox acquisition: searchForSync (LTS template, metric, plateau, LTS refinement, coarse CFO, noise-floor state)
+    for mod, rate in ((po.QAM16, po.R1_2), (po.DQPSK, po.R1_4)):
+        a, b = O.cox_lts_template(mod, rate), R.cox_lts_template(mod, rate)
+        check(f"cox LTS passband template mod={mod} rate={rate}", bits_equal(a[0], b[0]) and bits_equal(a[1], b[1]))
+    ok, n_det, worst = True, 0, ""
+    for ci, (buf_len, off, snr_db, cfo, thr, nf0, *var) in enumerate(cox_cases()):
+        x = cox_test_buffer(R, buf_len, off, snr_db, cfo, rng, var[0] if var else 0)
+        (a, na), (b, nb) = O.cox_search(x, thr, nf0), R.cox_search(x, thr, nf0)
+        same = bits_equal(a, b) and bits_equal([na], [nb])
+        ok &= same
+        if not same and not worst:
+            worst = f"len={buf_len} off={off} snr={snr_db} cfo={cfo} oracle={a},{na} ref={b},{nb}"
+        n_det += int(b[0])
+    check(f"cox_search ({n_det}/{len(cox_cases())} found by ref)", ok, worst)
 
     print("\n%s: %d failing group(s)" % ("PINNED" if fails == 0 else "MISMATCH", fails))
     return 1 if fails else 0

@@ -52,6 +52,61 @@ def chirp_buffer(chirp, case, idx):
     return x, zlib.crc32(x.tobytes())
 
 
+# (buffer length, preamble offset (<0: noise only), snr dB, cfo Hz, threshold, initial noise floor, variant)
+COX_CASES = [(30000, 0, 30, 0.0, 0.8, 0.0, 0), (30000, 5000, 20, 12.5, 0.8, 0.0, 0), (40000, 12000, 10, -30.0, 0.8, 0.0, 0),
+             (26000, 7777, 15, -8.0, 0.7, 1e-4, 0), (50000, 30000, 25, 0.0, 0.8, 0.0, 0), (20000, 15000, 20, 0.0, 0.8, 0.0, 0),
+             (9215, 0, 20, 0.0, 0.8, 0.0, 0), (3999, 0, 20, 0.0, 0.8, 0.0, 0), (30000, 4000, 30, 0.0, 0.95, 0.0, 0),
+             (30000, -1, 20, 0.0, 0.8, 0.0, 0), (9300, 100, 25, 5.0, 0.8, 0.0, 0), (16000, 500, 25, 5.0, 0.8, 0.0, 0),
+             (60000, 2000, 30, 0.0, 0.8, 0.0, 1), (60000, 6000, 22, 15.0, 0.8, 0.0, 1), (30000, 2000, 18, -20.0, 0.6, 0.0, 0),
+             (30000, 9000, 40, 45.0, 0.8, 0.0, 0), (24000, 64, 25, 0.0, 0.8, 0.0, 0), (30000, 2000, 28, 0.0, 0.8, 5e-3, 0),
+             (9216, 0, 30, 0.0, 0.8, 0.0, 0), (9217, 0, 30, 0.0, 0.8, 0.0, 0), (12000, 1000, 30, 0.0, 0.8, 0.0, 0),
+             (40000, 500, 30, 0.0, 0.8, 0.0, 2), (40000, 3000, 24, -10.0, 0.8, 0.0, 2)]
+
+
+def cox_buffer(tx, case, idx):
+    """tx = Schmidl-Cox preamble + one modulated frame (float32).  variant 1: the STS part alone (a plateau the
+    LTS refinement has to judge), silence, then the complete transmission.  variant 2: an out-of-band 10 kHz tone
+    burst first (Schmidl-Cox metric ~1 over a long plateau, LTS confirmation fails: the search must carry on)."""
+    import zlib
+    from check_against_ref import zc_test_buffer
+    buf_len, off, snr_db, cfo = int(case[0]), int(case[1]), float(case[2]), float(case[3])
+    rng = np.random.default_rng(9500 + idx)
+    if int(case[6]) == 1:
+        tx = np.concatenate([tx[:5 * 1152], np.zeros(12 * 1152, np.float32), tx])
+    if int(case[6]) == 2:
+        tone = (0.3 * np.sin(2 * np.pi * 10000.0 * np.arange(9000) / 48000.0)).astype(np.float32)
+        tx = np.concatenate([tone, np.zeros(3 * 1152, np.float32), tx])
+    if off < 0:
+        rms = np.sqrt(np.mean(tx[tx != 0].astype(np.float64) ** 2))
+        x = rng.normal(0, rms * 10 ** (-snr_db / 20.0), buf_len).astype(np.float32)
+    else:
+        x = zc_test_buffer(tx, buf_len, off, snr_db, cfo, rng)
+    return x, zlib.crc32(x.tobytes())
+
+
+def cox_fixture(R):
+    """OFDM-COX: the reference's preamble + frame audio, LTS passband templates, and searchForSync results
+    (found, first-LTS position, cfo, noise floor after) for buffers rebuilt from the recipe."""
+    rng = np.random.default_rng(515)
+    rec = {"cases": np.array(COX_CASES, np.float32)}
+    for name, mod, rate in (("qam16_r12", po.QAM16, po.R1_2), ("dqpsk_r14", po.DQPSK, po.R1_4)):
+        tI, tQ = R.cox_lts_template(mod, rate)
+        rec[f"tI_{name}"], rec[f"tQ_{name}"] = tI, tQ
+        rec[f"preamble_{name}"] = R.cox_transmit(None, mod, rate)
+    coded = rng.integers(0, 256, 324, dtype=np.uint8)
+    tx = R.cox_transmit(coded)
+    rec["tx"] = tx
+    crcs, res = [], []
+    for i, case in enumerate(COX_CASES):
+        x, crc = cox_buffer(tx, case, i)
+        out, nf = R.cox_search(x, float(case[4]), float(case[5]))
+        crcs.append(crc)
+        res.append(np.concatenate([out, [nf]]).astype(np.float32))
+    rec["buffer_crc"] = np.array(crcs, np.uint32)
+    rec["results"] = np.stack(res)
+    return rec
+
+
 MCDPSK_CASES = [(10, 1, 1, 20.0, 0.0, 0.0), (10, 1, 1, 0.0, 0.0, 0.0), (10, 2, 1, 8.0, 0.0, 0.0), (10, 1, 2, -3.0, 0.0, 0.0),
                 (10, 1, 4, -6.0, 0.0, 0.0), (8, 2, 1, 15.0, 6.5, 0.4), (10, 1, 1, 5.0, -12.0, -1.1), (5, 2, 2, 6.0, 0.0, 0.0)]
 
@@ -226,6 +281,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "chirp_sync.npz"), **rec)
     np.savez_compressed(os.path.join(OUT, "mcdpsk.npz"), **mcdpsk_fixture(R))
     np.savez_compressed(os.path.join(OUT, "lts_sync.npz"), **lts_fixture(R, O))
+    np.savez_compressed(os.path.join(OUT, "cox_sync.npz"), **cox_fixture(R))
     print("done ->", OUT)
     return 0
 

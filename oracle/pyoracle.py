@@ -82,6 +82,8 @@ class Oracle:
         L.ro_chirp_generate.argtypes = [_f, C.c_int]
         L.ro_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
         L.ro_detect_data_sync.argtypes = [_f, C.c_int, C.c_float, C.c_float, _f]
+        L.ro_cox_search.argtypes = [C.POINTER(Geom), _f, C.c_int, C.c_float, _f, _f]
+        L.ro_cox_lts_template.argtypes = [C.POINTER(Geom), _f, _f]
         L.ro_mcdpsk_modulate.argtypes = [C.c_int, C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
         L.ro_mcdpsk_demod.argtypes = [C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _f, C.c_int, _f]
         self._geoms = {}
@@ -110,6 +112,19 @@ class Oracle:
         out = np.zeros(4, np.float32)
         self.lib.ro_detect_data_sync(fp(x), len(x), known_cfo, threshold, fp(out))
         return out
+
+    def cox_search(self, samples, threshold=0.8, noise_floor=0.0, mod=QAM16, rate=R1_2):
+        """OFDMDemodulator::searchForSync -> (float32[3] {found, first-LTS position, cfo_hz}, noise floor after)"""
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(3, np.float32)
+        nf = np.array([noise_floor], np.float32)
+        self.lib.ro_cox_search(C.byref(self.geom(mod, rate)), fp(x), len(x), threshold, fp(nf), fp(out))
+        return out, float(nf[0])
+
+    def cox_lts_template(self, mod=QAM16, rate=R1_2):
+        tI, tQ = np.zeros(1152, np.float32), np.zeros(1152, np.float32)
+        self.lib.ro_cox_lts_template(C.byref(self.geom(mod, rate)), fp(tI), fp(tQ))
+        return tI, tQ
 
     def mcdpsk_modulate(self, nc, bps, spreading, data):
         data = np.ascontiguousarray(data, np.uint8)
@@ -250,7 +265,30 @@ class Ref:
         L.ref_mcdpsk_demod.argtypes = [C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _f, C.c_int, _f]
         L.ref_zc_generate.argtypes = [C.c_int, _f, C.c_int]
         L.ref_zc_detect.argtypes = [_f, C.c_int, C.c_float, C.c_int, C.c_float, _f]
+        L.ref_cox_search.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, _f, _f]
+        L.ref_cox_transmit.argtypes = [C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
+        L.ref_cox_lts_template.argtypes = [C.c_int, C.c_int, _f, _f]
         L.ref_quiet()
+
+    def cox_search(self, samples, threshold=0.8, noise_floor=0.0, mod=QAM16, rate=R1_2):
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.zeros(3, np.float32)
+        nf = np.array([noise_floor], np.float32)
+        self.lib.ref_cox_search(mod, rate, fp(x), len(x), threshold, fp(nf), fp(out))
+        return out, float(nf[0])
+
+    def cox_transmit(self, coded=None, mod=QAM16, rate=R1_2):
+        """Schmidl-Cox preamble (guard + 4 STS + 2 LTS) followed by the modulated coded bytes (optional)."""
+        coded = np.zeros(0, np.uint8) if coded is None else np.ascontiguousarray(coded, np.uint8)
+        out = np.zeros(200000, np.float32)
+        n = self.lib.ref_cox_transmit(mod, rate, up(coded), len(coded), fp(out), len(out))
+        assert n > 0, n
+        return out[:n].copy()
+
+    def cox_lts_template(self, mod=QAM16, rate=R1_2):
+        tI, tQ = np.zeros(1152, np.float32), np.zeros(1152, np.float32)
+        assert self.lib.ref_cox_lts_template(mod, rate, fp(tI), fp(tQ)) == 1152
+        return tI, tQ
 
     def zc_generate(self, root):
         out = np.zeros(4096, np.float32)

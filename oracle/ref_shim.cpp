@@ -48,6 +48,7 @@
 #include "psk/multi_carrier_dpsk.hpp"
 #define private public
 #include "waveform/ofdm_chirp_waveform.hpp"
+#include "waveform/ofdm_cox_waveform.hpp"
 #undef private
 
 using namespace ultra;
@@ -268,6 +269,42 @@ int ref_detect_data_sync(int mod, int rate, const float* samples, int n, float k
     return ok ? 1 : 0;
 }
 
+// Schmidl-Cox acquisition (demodulator.cpp:1450-1542).  noise_inout = Impl::noise_floor_energy before / after.
+int ref_cox_search(int mod, int rate, const float* samples, int n, float thr, float* noise_inout, float* out3) {
+    ref_quiet();
+    OFDMNvisWaveform rx(named_config(mod, rate));
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));   // pilot spacing as the waveform sets it
+    if (noise_inout) rx.demodulator_->impl_->noise_floor_energy = *noise_inout;
+    SyncResult r;
+    bool ok = rx.detectSync(SampleSpan(samples, n), r, thr);                    // -> OFDMDemodulator::searchForSync
+    if (noise_inout) *noise_inout = rx.demodulator_->impl_->noise_floor_energy;
+    out3[0] = ok ? 1.0f : 0.0f; out3[1] = ok ? static_cast<float>(r.start_sample) : 0.0f; out3[2] = ok ? r.cfo_hz : 0.0f;
+    return ok ? 1 : 0;
+}
+// Full Schmidl-Cox preamble (guard + 4 STS + 2 LTS, modulator.cpp:479-532) followed by one modulated frame of coded bytes.
+int ref_cox_transmit(int mod, int rate, const uint8_t* coded, int n_coded, float* out, int max_n) {
+    ref_quiet();
+    OFDMNvisWaveform tx(named_config(mod, rate));
+    tx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    Samples pre = tx.generatePreamble();
+    Samples dat;
+    if (n_coded > 0) dat = tx.modulate(Bytes(coded, coded + n_coded));
+    int n = static_cast<int>(pre.size() + dat.size());
+    if (n > max_n) return -n;
+    std::memcpy(out, pre.data(), pre.size() * sizeof(float));
+    if (!dat.empty()) std::memcpy(out + pre.size(), dat.data(), dat.size() * sizeof(float));
+    return n;
+}
+int ref_cox_lts_template(int mod, int rate, float* tI, float* tQ) {
+    ref_quiet();
+    OFDMNvisWaveform rx(named_config(mod, rate));
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    auto& im = *rx.demodulator_->impl_;
+    int n = static_cast<int>(im.lts_passband_I.size());
+    std::memcpy(tI, im.lts_passband_I.data(), n * sizeof(float));
+    std::memcpy(tQ, im.lts_passband_Q.data(), n * sizeof(float));
+    return n;
+}
 // Dual chirp (chirp_sync.hpp:352-512); out = {success, up_start, down_start, cfo_hz, up_corr, down_corr}
 int ref_chirp_detect(const float* samples, int n, float thr, float* out6) {
     ref_quiet();

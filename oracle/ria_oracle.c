@@ -1499,3 +1499,153 @@ int ro_decode_fixed_frame(const float* llr, int n, int rate, int ch_deint, int b
     for (int cw = 0; cw < 4; ++cw) if (ok_out[cw]) memcpy(data_out + cw * bpc, cwd[cw], (size_t)bpc);
     return g_sort_unpinned ? -1 - good : good;
 }
+
+/* ------------------------------------------------------------------ Schmidl-Cox acquisition
+ * OFDMDemodulator::searchForSync          src/ofdm/demodulator.cpp:1450-1542
+ * Impl::hasMinimumEnergy                  src/ofdm/ofdm_sync.cpp:20-50
+ * Impl::toAnalytic                        src/ofdm/ofdm_sync.cpp:56-86   (FFT Hilbert, fft_len == len == 1024)
+ * Impl::measureSchmidlCoxCorrelation      src/ofdm/ofdm_sync.cpp:118-163
+ * Impl::estimateCoarseCFO                 src/ofdm/ofdm_sync.cpp:230-261
+ * Impl::refineLTSTiming                   src/ofdm/ofdm_sync.cpp:386-484
+ * LTS passband templates                  src/ofdm/demodulator.cpp:108-141
+ * Pinned bit-for-bit against oracle/_ref by oracle/check_against_ref.py. */
+static void cox_analytic(const float* s, cf* out) { /* toAnalytic, len 1024 */
+    for (int i = 0; i < RO_FFT; ++i) out[i] = cf_mk(s[i], 0.0f);
+    ro_fft(out, 0);
+    for (int i = 1; i < RO_FFT / 2; ++i) out[i] = cf_mk(out[i].re * 2.0f, out[i].im * 2.0f);
+    for (int i = RO_FFT / 2 + 1; i < RO_FFT; ++i) out[i] = cf_mk(0.0f, 0.0f);
+    ro_fft(out, 1);
+}
+static float cox_metric(const float* x, int n, int offset) { /* measureSchmidlCoxCorrelation */
+    const int cp = RO_SYM - RO_FFT, half = RO_FFT / 2;
+    if (offset + cp + RO_FFT > n) return 0.0f;
+    const float* d = x + offset + cp;
+    float dc_sum = 0.0f;
+    for (int i = 0; i < RO_FFT; ++i) dc_sum += d[i];
+    float dc = dc_sum / (float)RO_FFT;
+    static float tmp[RO_FFT];
+    static cf an[RO_FFT];
+    for (int i = 0; i < RO_FFT; ++i) tmp[i] = d[i] - dc;
+    cox_analytic(tmp, an);
+    cf P = cf_mk(0.0f, 0.0f);
+    float R1 = 0.0f, R2 = 0.0f;
+    for (int i = 0; i < half; ++i) {
+        P = cf_add(P, cf_mul(cf_conj(an[i]), an[i + half]));
+        R1 += cf_norm(an[i]);
+        R2 += cf_norm(an[i + half]);
+    }
+    float norm = sqrtf(R1 * R2);
+    if (norm < 1e-10f) return 0.0f;
+    return cf_abs(P) / norm;
+}
+static int cox_has_energy(const float* x, int n, int offset, int window, float* nf) { /* hasMinimumEnergy */
+    if (offset + window > n) return 0;
+    float sum_sq = 0.0f;
+    int count = 0;
+    for (int i = 0; i < window; i += 16) { float s = x[offset + i]; sum_sq += s * s; ++count; }
+    float energy = sum_sq / (float)count;
+    if (*nf < 1e-20f) *nf = energy * 0.1f;
+    if (energy < *nf) *nf = energy;
+    else if (energy < *nf * 3.0f) *nf = (1.0f - 0.01f) * *nf + 0.01f * energy;
+    return energy >= *nf * 4.0f;
+}
+static float cox_coarse_cfo(const float* x, int n, int sync_offset) { /* estimateCoarseCFO */
+    const int cp = RO_SYM - RO_FFT, half = RO_FFT / 2;
+    int ds = sync_offset + cp;
+    if (ds + RO_FFT > n) return 0.0f;
+    static cf an[RO_FFT];
+    cox_analytic(x + ds, an);
+    cf P = cf_mk(0.0f, 0.0f);
+    for (int i = 0; i < half; ++i) P = cf_add(P, cf_mul(cf_conj(an[i]), an[i + half]));
+    float phase = atan2f(P.im, P.re);
+    float cfo = (float)((double)(phase * 48000.0f) / (M_PI * (double)RO_FFT));
+    float max_cfo = (float)(48000 / RO_FFT); /* integer division in the reference: uint32_t / size_t */
+    return fmaxf_(-max_cfo, fminf_(max_cfo, cfo));
+}
+void ro_cox_lts_template(const ro_geom* g, float* tI, float* tQ) { /* demodulator.cpp:108-141 */
+    static cf f[RO_FFT];
+    for (int i = 0; i < RO_FFT; ++i) f[i] = cf_mk(0.0f, 0.0f);
+    for (int i = 0; i < g->n_data; ++i) f[g->data_idx[i]] = cf_mk(g->sync_re[i % RO_NCAR], g->sync_im[i % RO_NCAR]);
+    for (int i = 0; i < g->n_pilot; ++i) f[g->pilot_idx[i]] = cf_mk(g->pilot_seq[i], 0.0f);
+    ro_fft(f, 1);
+    const int cp = RO_SYM - RO_FFT;
+    ro_nco nco;
+    ro_nco_init(&nco, 1500.0f, 48000.0f);
+    for (int i = 0; i < RO_SYM; ++i) {
+        cf b = (i < cp) ? f[RO_FFT - cp + i] : f[i - cp];
+        cf m = cf_mul(b, ro_nco_next(&nco));
+        tI[i] = m.re; tQ[i] = m.im;
+    }
+}
+static float cox_lts_corr(const float* x, int n, long long offset, const float* tI, const float* tQ, float eref) {
+    if (offset + RO_SYM > n) return 0.0f;
+    float cI = 0.0f, cQ = 0.0f, erx = 0.0f;
+    for (int i = 0; i < RO_SYM; ++i) {
+        float s = x[offset + i];
+        cI += s * tI[i];
+        cQ += s * tQ[i];
+        erx += s * s;
+    }
+    float mag = sqrtf(cI * cI + cQ * cQ), norm = sqrtf(erx * eref);
+    return (norm > 1e-6f) ? mag / norm : 0.0f;
+}
+/* returns refined LTS start, or -1 for the reference's SIZE_MAX */
+static long long cox_refine_lts(const float* x, int n, int coarse_sts, const float* tI, const float* tQ) {
+    const int L = RO_SYM, BACK = 3 * L, FWD = L / 2;
+    long long coarse = (long long)coarse_sts + 4 * L;
+    if (coarse < BACK || coarse + FWD + L > n) return coarse;
+    float eref = 0.0f;
+    for (int i = 0; i < L; ++i) { eref += tI[i] * tI[i]; eref += tQ[i] * tQ[i]; }
+    eref *= 0.5f;
+    float best = 0.0f;
+    long long best_off = coarse;
+    for (int d = -BACK; d <= FWD; ++d) {
+        float c = cox_lts_corr(x, n, coarse + d, tI, tQ, eref);
+        if (c > best) { best = c; best_off = coarse + d; }
+    }
+    if (best_off >= L) {
+        long long prev = best_off - L;
+        if (prev >= coarse - BACK) {
+            float pc = cox_lts_corr(x, n, prev, tI, tQ, eref);
+            if (pc >= best * 0.92f) { best_off = prev; best = pc; }
+        }
+    }
+    if (best < 0.05f) return -1;
+    return best_off;
+}
+/* out3 = {found, position (first LTS symbol), cfo_hz}; *noise_floor is Impl::noise_floor_energy (0 for a fresh demodulator)
+ * and is updated as the reference's member would be. */
+int ro_cox_search(const ro_geom* g, const float* x, int n, float threshold, float* noise_floor, float* out3) {
+    out3[0] = out3[1] = out3[2] = 0.0f;
+    const int L = RO_SYM, total = 6 * L, window = 2 * L;
+    if (n < 4000) return 0;
+    if (n < total + window) return 0;
+    static float tI[RO_SYM], tQ[RO_SYM];
+    ro_cox_lts_template(g, tI, tQ);
+    float nf = noise_floor ? *noise_floor : 0.0f;
+    int found = 0;
+    const int search_end = n - total - window;
+    for (int i = 0; i < search_end; i += 64) {
+        if (!cox_has_energy(x, n, i, window, &nf)) { i += window / 2 - 64; continue; }
+        float corr = cox_metric(x, n, i);
+        if (corr > threshold) {
+            int plateau = 0, peak_pos = i;
+            float peak = corr;
+            for (int j = 0; j <= 300 && i + j + total < n; j += 8) {
+                float c = cox_metric(x, n, i + j);
+                if (c >= 0.90f) ++plateau;
+                if (c > peak) { peak = c; peak_pos = i + j; }
+            }
+            if (plateau >= 15) {
+                long long lts = cox_refine_lts(x, n, peak_pos, tI, tQ);
+                if (lts >= 0) {
+                    found = 1;
+                    out3[0] = 1.0f; out3[1] = (float)lts; out3[2] = cox_coarse_cfo(x, n, peak_pos);
+                    break;
+                }
+            }
+        }
+    }
+    if (noise_floor) *noise_floor = nf;
+    return found;
+}

@@ -120,3 +120,13 @@ int ro_detect_data_sync(const float* x, int n, float known_cfo_hz, float thresho
 int ro_chase_store(float* existing, int* combine_count, int decoded, const float* soft);
 
 #endif
+/* Schmidl-Cox acquisition: OFDMDemodulator::searchForSync (src/ofdm/demodulator.cpp:1450-1542, ofdm_sync.cpp).
+ * out3 = {found, first-LTS position, cfo_hz}; noise_floor in/out = Impl::noise_floor_energy (may be NULL = 0). */
+#ifdef __cplusplus
+extern "C" {
+#endif
+void ro_cox_lts_template(const ro_geom* g, float* tI, float* tQ);
+int ro_cox_search(const ro_geom* g, const float* x, int n, float threshold, float* noise_floor, float* out3);
+#ifdef __cplusplus
+}
+#endif

@@ -149,6 +149,83 @@ inline std::vector<float> build_nco_table(int n, float freq = 1500.0f, float fs 
     return t;
 }
 
+// ---------------------------------------------------------------- Schmidl-Cox preamble / LTS template (host, built once)
+// FFT::inverse of the reference (fft.cpp:96-128): bit-reversal, radix-2 DIT with conjugated twiddles, 1/N scale.
+inline void host_ifft1024(std::vector<float>& re, std::vector<float>& im) {
+    const std::vector<float> tw = build_twiddles();
+    const int size = kFFT;
+    int j = 0;
+    for (int i = 0; i < size - 1; ++i) {
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+        int k = size / 2;
+        while (k <= j) { j -= k; k /= 2; }
+        j += k;
+    }
+    for (int len = 2; len <= size; len *= 2) {
+        const int half = len / 2, step = size / len;
+        for (int i = 0; i < size; i += len)
+            for (int k = 0; k < half; ++k) {
+                const float wr = tw[2 * k * step], wi = -tw[2 * k * step + 1];
+                const float br = re[i + k + half], bi = im[i + k + half];
+                const float tr = wr * br - wi * bi, ti = wr * bi + wi * br;
+                re[i + k + half] = re[i + k] - tr; im[i + k + half] = im[i + k] - ti;
+                re[i + k] = re[i + k] + tr;        im[i + k] = im[i + k] + ti;
+            }
+    }
+    const float scale = 1.0f / static_cast<float>(size);
+    for (int i = 0; i < size; ++i) { re[i] *= scale; im[i] *= scale; }
+}
+// one OFDM training symbol with cyclic prefix, complex baseband; sts = even FFT bins of the data carriers only
+// (modulator.cpp:298-329 createSchmidlCoxSTS) else the LTS (data carriers <- ZC-59 by data ordinal, pilots <- pilot
+// sequence; modulator.cpp:217-270 / demodulator.cpp:108-128)
+inline void build_training_symbol(const CarrierPlan& p, bool sts, std::vector<float>& re, std::vector<float>& im) {
+    std::vector<float> fr(kFFT, 0.0f), fi(kFFT, 0.0f);
+    for (int i = 0; i < p.n_data; ++i) {
+        if (sts && (p.data_bin[i] % 2) != 0) continue;
+        fr[p.data_bin[i]] = p.sync_re[i % kCarriers]; fi[p.data_bin[i]] = p.sync_im[i % kCarriers];
+    }
+    if (!sts) for (int i = 0; i < p.n_pilot; ++i) { fr[p.pilot_bin[i]] = p.pilot_seq[i]; fi[p.pilot_bin[i]] = 0.0f; }
+    host_ifft1024(fr, fi);
+    const int cp = kSym - kFFT;
+    re.resize(kSym); im.resize(kSym);
+    for (int i = 0; i < kSym; ++i) { const int k = (i < cp) ? kFFT - cp + i : i - cp; re[i] = fr[k]; im[i] = fi[k]; }
+}
+struct CoxTemplate { std::vector<float> tI, tQ; float energy_ref = 0.0f; };
+// OFDMDemodulator::Impl::generateSequences (demodulator.cpp:108-141) + the template energy of refineLTSTiming
+// (ofdm_sync.cpp:405-411)
+inline CoxTemplate build_cox_template(const CarrierPlan& p) {
+    CoxTemplate t;
+    std::vector<float> re, im;
+    build_training_symbol(p, false, re, im);
+    const std::vector<float> nco = build_nco_table(kSym);
+    t.tI.resize(kSym); t.tQ.resize(kSym);
+    for (int i = 0; i < kSym; ++i) {
+        const float c = nco[2 * i], s = nco[2 * i + 1];
+        t.tI[i] = re[i] * c - im[i] * s;
+        t.tQ[i] = re[i] * s + im[i] * c;
+    }
+    float e = 0.0f;
+    for (int i = 0; i < kSym; ++i) { e += t.tI[i] * t.tI[i]; e += t.tQ[i] * t.tQ[i]; }
+    t.energy_ref = e * 0.5f;
+    return t;
+}
+// OFDMModulator::generatePreamble (modulator.cpp:479-532): one symbol of silence, the STS four times, the LTS twice;
+// complexToReal (:272-282) runs the TX mixer once over the STS and once over the LTS (the copies repeat the samples).
+inline std::vector<float> build_cox_preamble(const CarrierPlan& p, float output_scale = 40.0f) {
+    std::vector<float> out(static_cast<size_t>(kSym), 0.0f);
+    const std::vector<float> nco = build_nco_table(2 * kSym);
+    for (int part = 0; part < 2; ++part) {
+        std::vector<float> re, im, real(kSym);
+        build_training_symbol(p, part == 0, re, im);
+        for (int i = 0; i < kSym; ++i) {
+            const float c = nco[2 * (part * kSym + i)], s = nco[2 * (part * kSym + i) + 1];
+            real[i] = (re[i] * c - im[i] * s) * output_scale;
+        }
+        for (int r = 0; r < (part == 0 ? 4 : 2); ++r) out.insert(out.end(), real.begin(), real.end());
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------- LDPC H = [H_data | I]
 struct LdpcCode {
     int rate = 0, k = 0, m = 0, n = 0, n_edges = 0, max_col_deg = 0;

@@ -27,6 +27,7 @@
 #include "tx_kernels.hip.h"
 #include "sync_kernels.hip.h"
 #include "mcdpsk_kernels.hip.h"
+#include "cox_kernels.hip.h"
 
 using namespace ria;
 
@@ -50,6 +51,8 @@ struct ria_gpu {
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
     std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
+    // Schmidl-Cox acquisition: LTS passband templates (built at first use) and the metric-table workspace
+    void* d_cox_tI = nullptr; void* d_cox_tQ = nullptr; float cox_energy_ref = 0.0f; void* d_cox_ws = nullptr; size_t cox_ws_floats = 0;
     void* d_demod_const = nullptr;
     void* d_tx_const = nullptr;
     // workspace
@@ -374,6 +377,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
+    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
@@ -968,9 +972,64 @@ int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t s
     return RIA_OK;
 }
 
+int ria_gpu_sync_cox_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int buf_len, int n_buffers,
+                           float threshold, const float* noise_floor_dev, ria_cox_result* out_dev, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_buffers == 0) return RIA_OK;
+    if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || buf_len > kCoxMaxBuf || stride < buf_len)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_cox_batch: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->d_cox_tI) {
+        const CoxTemplate t = build_cox_template(h->plan);
+        HIP_TRY(h, upload(&h->d_cox_tI, t.tI));
+        HIP_TRY(h, upload(&h->d_cox_tQ, t.tQ));
+        h->cox_energy_ref = t.energy_ref;
+    }
+    const bool searched = buf_len >= kCoxMinSearch && buf_len >= kCoxTotal + kCoxWindow;
+    const int nM = searched ? cox_n_metric(buf_len) : 0, nE = searched ? cox_n_energy(buf_len) : 0;
+    const size_t per = 2 * static_cast<size_t>(nM) + static_cast<size_t>(nE);
+    // buffers per pass: the tables of one pass stay under 256 MiB and the grid's y extent under 65536
+    int chunk = n_buffers;
+    if (per) chunk = static_cast<int>(std::min<size_t>(chunk, std::max<size_t>(1, (size_t(64) << 20) / per)));
+    chunk = std::min(chunk, 32768);
+    const size_t need = per * static_cast<size_t>(chunk) + 16;
+    if (need > h->cox_ws_floats) {
+        if (h->d_cox_ws) { HIP_TRY(h, hipStreamSynchronize(s)); (void)hipFree(h->d_cox_ws); }
+        h->d_cox_ws = nullptr; h->cox_ws_floats = 0;
+        HIP_TRY(h, hipMalloc(&h->d_cox_ws, need * sizeof(float)));
+        h->cox_ws_floats = need;
+    }
+    for (int first = 0; first < n_buffers; first += chunk) {
+        const int nb = std::min(chunk, n_buffers - first);
+        CoxArgs A{};
+        A.samples = samples_dev + static_cast<int64_t>(first) * stride; A.stride = stride; A.buf_len = buf_len; A.n_buffers = nb;
+        A.threshold = threshold; A.noise_in = noise_floor_dev ? noise_floor_dev + first : nullptr;
+        A.twiddle = static_cast<const float2*>(h->d_twiddle);
+        A.tI = static_cast<const float*>(h->d_cox_tI); A.tQ = static_cast<const float*>(h->d_cox_tQ); A.energy_ref = h->cox_energy_ref;
+        float* ws = static_cast<float*>(h->d_cox_ws);
+        A.dc = ws; A.metric = ws + static_cast<size_t>(nM) * nb; A.energy = ws + 2 * static_cast<size_t>(nM) * nb;
+        A.nM = nM; A.nE = nE; A.out = out_dev + first;
+        if (nM > 0) {
+            hipLaunchKernelGGL(cox_prepare_kernel, dim3((nM + 255) / 256, nb), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(cox_metric_kernel, dim3((nM + 3) / 4, nb), dim3(256), 0, s, A);
+        }
+        hipLaunchKernelGGL(cox_scan_kernel, dim3(nb), dim3(1024), 0, s, A);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_cox_preamble(ria_gpu_handle h, float* out_host, int max_n) {
+    if (!h || !out_host) return RIA_ERR_INVALID;
+    std::vector<float> p = build_cox_preamble(h->plan);
+    if (static_cast<int>(p.size()) > max_n) return -static_cast<int>(p.size());
+    std::memcpy(out_host, p.data(), p.size() * sizeof(float));
+    return static_cast<int>(p.size());
+}
+
 int ria_gpu_sync_host(ria_gpu_handle h, int kind, const float* samples_host, int n_samples, float threshold, float param,
                       uint32_t root_mask, void* result_out) {
-    if (!h || !samples_host || !result_out || n_samples < 0 || kind < 0 || kind > 2) return RIA_ERR_INVALID;
+    if (!h || !samples_host || !result_out || n_samples < 0 || kind < 0 || kind > 3) return RIA_ERR_INVALID;
     const size_t need = static_cast<size_t>(n_samples) * sizeof(float) + 64;
     if (need > h->sync_host_bytes) {
         if (h->d_sync_host) (void)hipFree(h->d_sync_host);
@@ -987,6 +1046,7 @@ int ria_gpu_sync_host(ria_gpu_handle h, int kind, const float* samples_host, int
     int rc;
     if (kind == 0) rc = ria_gpu_sync_chirp_batch(h, d_x, n_samples, n_samples, 1, threshold, static_cast<ria_chirp_result*>(d_res), nullptr);
     else if (kind == 1) rc = ria_gpu_sync_lts_batch(h, d_x, n_samples, n_samples, 1, d_param, threshold, static_cast<ria_lts_result*>(d_res), nullptr);
+    else if (kind == 3) rc = ria_gpu_sync_cox_batch(h, d_x, n_samples, n_samples, 1, threshold, d_param, static_cast<ria_cox_result*>(d_res), nullptr);
     else rc = ria_gpu_sync_zc_batch(h, d_x, n_samples, n_samples, 1, threshold, root_mask, d_param, static_cast<ria_zc_result*>(d_res), nullptr);
     if (rc != RIA_OK) return rc;
     HIP_TRY(h, hipDeviceSynchronize());

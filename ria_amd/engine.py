@@ -211,6 +211,26 @@ class RxEngine:
                                                     _ptr(out), _stream_ptr()))
         return self._status_array(out, self.LTS_RESULT)
 
+    COX_RESULT = np.dtype([("found", "<i4"), ("start_sample", "<i4"), ("cfo_hz", "<f4"), ("noise_floor", "<f4"),
+                           ("sts_position", "<i4"), ("reserved", "<i4", 3)])
+
+    def sync_cox(self, buffers, threshold=0.8, noise_floor=None):
+        """OFDMDemodulator::searchForSync (Schmidl-Cox, OFDM-COX waveform) over a batch: buffers float32
+        [n, buf_len] on the device; noise_floor float32 [n] = the demodulator's tracker before the call."""
+        n, buf_len = buffers.shape
+        assert buffers.dtype == torch.float32 and buffers.is_contiguous()
+        out = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_sync_cox_batch(self.h, _ptr(buffers), buf_len, buf_len, n, float(threshold), _ptr(noise_floor),
+                                                    _ptr(out), _stream_ptr()))
+        return self._status_array(out, self.COX_RESULT)
+
+    def cox_preamble(self):
+        out = np.zeros(10000, np.float32)
+        n = self.lib.ria_gpu_cox_preamble(self.h, out.ctypes.data, len(out))
+        if n < 0:
+            raise capi.RiaError("cox_preamble: buffer too small")
+        return out[:n].copy()
+
     MCDPSK_STATUS = np.dtype([("cfo_hz", "<f4"), ("fading_index", "<f4"), ("freq_fading_index", "<f4"),
                               ("temporal_fading_index", "<f4"), ("training_cfo_residual", "<f4"), ("n_llr", "<i4"),
                               ("valid_symbols", "<i4"), ("reserved", "<i4")])

@@ -169,7 +169,7 @@ public:
     int getMinSamplesForFrame() const { return getMinSamplesForCWCount(4); }
     const ria_gpu_geometry& geometry() const { return gpu_->geo(); }
 
-private:
+protected:
     int device_;
     Modulation mod_ = Modulation::QAM16;
     CodeRate rate_ = CodeRate::R1_2;
@@ -178,6 +178,37 @@ private:
     float cfo_hz_ = 0.0f, last_cfo_ = 0.0f, last_snr_ = 0.0f, fading_index_ = 0.0f;
     size_t abs_pos_ = 0, training_start_ = 0;
     bool has_abs_ = false, synced_ = false, burst_marker_ = false;
+};
+
+// OFDM-COX: the same demodulator behind Schmidl-Cox acquisition (src/waveform/ofdm_cox_waveform.cpp).  process()
+// is the OFDM-CHIRP one (ofdm_cox_waveform.cpp:164-214 drives the same processPresynced); detectSync() is
+// OFDMDemodulator::searchForSync on the GPU, the demodulator's noise-floor tracker carried from call to call as
+// the reference's member is (ofdm_sync.cpp:35-46); configure() starts a fresh demodulator (tracker = 0).
+class GpuOfdmCoxWaveform : public GpuOfdmChirpWaveform {
+public:
+    explicit GpuOfdmCoxWaveform(Modulation mod = Modulation::QAM16, CodeRate rate = CodeRate::R1_2, int device = 0)
+        : GpuOfdmChirpWaveform(mod, rate, device) {}
+    std::string getName() const { return "OFDM-COX (MI355X)"; }
+    void configure(Modulation mod, CodeRate rate) { GpuOfdmChirpWaveform::configure(mod, rate); noise_floor_ = 0.0f; }
+    std::vector<float> generatePreamble() {                                          // ofdm_cox_waveform.cpp:107-112
+        std::vector<float> p(8 * static_cast<size_t>(gpu_->geo().samples_per_symbol));
+        int n = ria_gpu_cox_preamble(gpu_->get(), p.data(), static_cast<int>(p.size()));
+        p.resize(n > 0 ? static_cast<size_t>(n) : 0);
+        return p;
+    }
+    bool detectSync(SampleSpan samples, SyncResult& result, float threshold = 0.8f) {  // ofdm_cox_waveform.cpp:125-158
+        ria_cox_result r{};
+        if (ria_gpu_sync_host(gpu_->get(), 3, samples.data(), static_cast<int>(samples.size()), threshold, noise_floor_, 0u, &r) != RIA_OK) return false;
+        noise_floor_ = r.noise_floor;
+        if (!r.found) return false;
+        result.detected = true; result.start_sample = r.start_sample; result.cfo_hz = r.cfo_hz;
+        result.has_training = true; result.correlation = 0.9f;
+        cfo_hz_ = r.cfo_hz; last_cfo_ = r.cfo_hz; synced_ = true;
+        training_start_ = static_cast<size_t>(r.start_sample);
+        return true;
+    }
+private:
+    float noise_floor_ = 0.0f;
 };
 
 // protocol::v2::decodeFixedFrame(interleaved_soft, rate, use_channel_deinterleave, bits_per_symbol)

@@ -19,6 +19,16 @@ int main(int argc, char** argv) {
     GpuOfdmChirpWaveform rx(mod, rate);
     GpuHandle dec(mod, rate);
     rx.reset();
+    if (argc > 7 && atoi(argv[7]) == 2) {   // OFDM-COX: generatePreamble + detectSync twice on the same object (the
+        GpuOfdmCoxWaveform cox(mod, rate);   // second call starts from the first one's noise floor, as the reference's does)
+        printf("%zu\n", cox.generatePreamble().size());
+        for (int pass = 0; pass < 2; ++pass) {
+            SyncResult r;
+            bool ok = cox.detectSync(SampleSpan{x.data(), x.size()}, r, static_cast<float>(atof(argv[4])));
+            printf("%d %d %.9g %.9g\n", ok ? 1 : 0, r.start_sample, r.cfo_hz, r.correlation);
+        }
+        return 0;
+    }
     if (argc > 7) {   // sync mode: detectDataSync / detectSync on the span, print the SyncResult, exit
         SyncResult r;
         bool ok = (atoi(argv[7]) == 1) ? rx.detectDataSync(SampleSpan{x.data(), x.size()}, r, static_cast<float>(atof(argv[4])), 0.5f)

@@ -75,3 +75,22 @@ def test_link_adaptation_ladder_matches_reference_grid(golden):
             assert L.ria_link_ofdm_code_rate(float(s), float(f)) == g["rate"][i, j]
             assert L.ria_link_cap_initial_rate(float(s), float(f), 4) == g["cap"][i, j, 0]
             assert L.ria_link_cap_initial_rate(float(s), float(f), 3) == g["cap"][i, j, 1]
+
+
+def test_host_built_cox_tables_match_reference_golden(golden, tmp_path):
+    """The LTS passband templates and the Schmidl-Cox preamble the library builds on the host
+    (ria_amd/csrc/host_tables.hpp: build_cox_template / build_cox_preamble) against the reference's
+    (demodulator.cpp:108-141, modulator.cpp:479-532), bit for bit, without a GPU."""
+    import subprocess
+    import numpy as np
+    exe = str(tmp_path / "htc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "helpers", "host_tables_check.cpp")])
+    g = golden("cox_sync")
+    for name, mod, rate in (("qam16_r12", 6, 2), ("dqpsk_r14", 2, 0)):
+        out = str(tmp_path / f"{name}.f32")
+        subprocess.check_call([exe, str(mod), str(rate), out])
+        a = np.fromfile(out, np.float32)
+        assert np.array_equal(a[:1152].view(np.uint32), g[f"tI_{name}"].view(np.uint32))
+        assert np.array_equal(a[1152:2304].view(np.uint32), g[f"tQ_{name}"].view(np.uint32))
+        assert np.array_equal(a[2305:].view(np.uint32), g[f"preamble_{name}"].view(np.uint32))

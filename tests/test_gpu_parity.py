@@ -328,6 +328,83 @@ def test_chirp_sync_matches_oracle_batch(oracle):
     assert n_ok >= 40
 
 
+def _cox_fields(r):
+    return np.stack([r["found"].astype(np.float32), r["start_sample"].astype(np.float32), r["cfo_hz"], r["noise_floor"]], axis=1)
+
+
+def test_cox_sync_matches_reference_golden(oracle, golden):
+    """ria_gpu_sync_cox_batch vs OFDMDemodulator::searchForSync results recorded from the reference (found, first-LTS
+    position, coarse CFO, noise floor after), bit-exact, incl. the buffers whose early candidates fail the LTS
+    confirmation; ria_gpu_cox_preamble vs the reference's generatePreamble; the single-buffer host form."""
+    import ctypes as C
+    from test_oracle_golden import _cox_cases
+    from ria_amd import capi
+    g = golden("cox_sync")
+    e = engine("QAM16", "R1_2")
+    assert np.array_equal(e.cox_preamble().view(np.uint32), g["preamble_qam16_r12"].view(np.uint32))
+    assert np.array_equal(engine("DQPSK", "R1_4").cox_preamble().view(np.uint32), g["preamble_dqpsk_r14"].view(np.uint32))
+    cases = _cox_cases(golden)
+    for i, (x, thr, nf0, r) in enumerate(cases):
+        out = _cox_fields(e.sync_cox(dev(x[None, :]), thr, dev(np.array([nf0], np.float32))))[0]
+        assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (i, out, r)
+    x, thr, nf0, r = cases[1]
+    res = np.zeros(1, e.COX_RESULT)
+    assert e.lib.ria_gpu_sync_host(e.h, 3, x.ctypes.data, len(x), C.c_float(thr), C.c_float(nf0), 0, res.ctypes.data) == 0
+    assert np.array_equal(_cox_fields(res)[0].view(np.uint32), r.view(np.uint32))
+
+
+def test_cox_sync_matches_oracle_batch(oracle, golden):
+    """A batch of capture buffers with random offsets / SNR / CFO / thresholds / initial noise floors (found and
+    not found, DQPSK R1/4 pilot layout too): GPU == oracle on every field."""
+    import gen_golden
+    import pyoracle as po
+    g = golden("cox_sync")
+    rng = np.random.default_rng(31337)
+    for mod, rate, name, po_mod, po_rate, tx in (("QAM16", "R1_2", "qam16_r12", po.QAM16, po.R1_2, g["tx"]),
+                                                ("DQPSK", "R1_4", "dqpsk_r14", po.DQPSK, po.R1_4, g["preamble_dqpsk_r14"])):
+        e = engine(mod, rate)
+        n, L = 40, 26000
+        bufs, thr_nf = [], []
+        for t in range(n):
+            off = int(rng.integers(0, 14000)) if t % 7 else -1
+            case = (L, off, (35, 25, 18, 12, 30)[t % 5], (-40.0, -12.5, 0.0, 7.0, 33.0)[(t // 5) % 5], 0.8, 0.0, (0, 0, 0, 2)[t % 4] if mod == "QAM16" else 0)
+            x, _ = gen_golden.cox_buffer(tx, case, 100 + t)
+            bufs.append(x)
+            thr_nf.append((0.8, (0.0, 0.0, 1e-4, 2e-3)[t % 4]))
+        X = np.stack(bufs)
+        nf = np.array([v for _, v in thr_nf], np.float32)
+        out = _cox_fields(e.sync_cox(dev(X), 0.8, dev(nf)))
+        n_found = 0
+        for i in range(n):
+            o3, nfa = oracle.cox_search(X[i], 0.8, float(nf[i]), po_mod, po_rate)
+            exp = np.concatenate([o3, [nfa]]).astype(np.float32)
+            assert np.array_equal(out[i].view(np.uint32), exp.view(np.uint32)), (mod, i, out[i], exp)
+            n_found += int(exp[0])
+        assert n_found >= n // 3, n_found
+
+
+def test_cox_sync_edge_cases(oracle):
+    """Empty batch, buffers below MIN_SEARCH_SAMPLES / below preamble + window (demodulator.cpp:1454,1466: not
+    found, noise floor untouched), silence, a constant, oversize rejected."""
+    import torch
+    e = engine("QAM16", "R1_2")
+    assert len(e.sync_cox(torch.zeros((0, 20000), dtype=torch.float32, device="cuda"))) == 0
+    rng = np.random.default_rng(3)
+    for L in (100, 3999, 4000, 9215):
+        r = e.sync_cox(dev(rng.normal(0, 0.1, (3, L)).astype(np.float32)), 0.8, dev(np.array([0.0, 1e-3, 5.0], np.float32)))
+        assert (r["found"] == 0).all() and np.array_equal(r["noise_floor"], np.array([0.0, 1e-3, 5.0], np.float32))
+    X = np.zeros((3, 12000), np.float32)
+    X[1] = 0.25
+    X[2] = rng.normal(0, 1e-3, 12000)
+    out = _cox_fields(e.sync_cox(dev(X), 0.8))
+    for i in range(3):
+        o3, nfa = oracle.cox_search(X[i], 0.8, 0.0)
+        exp = np.concatenate([o3, [nfa]]).astype(np.float32)
+        assert np.array_equal(out[i].view(np.uint32), exp.view(np.uint32)), (i, out[i], exp)
+    with pytest.raises(Exception):
+        e.sync_cox(torch.zeros((1, 240001), dtype=torch.float32, device="cuda"))
+
+
 def test_mcdpsk_demod_matches_reference_golden(oracle, golden):
     """ria_gpu_mcdpsk_demod_batch / ria_gpu_mcdpsk_modulate_host vs the reference's modulator audio (checksum),
     LLRs and fading indices (bit-exact)."""
@@ -720,3 +797,16 @@ def test_cpp_host_adaptor_drop_in(golden, tmp_path):
     x.tofile(fin)
     t = subprocess.check_output([exe, "6", "2", fin, "0", "0", "x", "0"]).decode().split()
     assert int(t[0]) == 1 and int(t[1]) == int(r[2]) + 24000 + 4800 and np.float32(float(t[3])) == r[3]
+    # OFDM-COX adaptor: detectSync twice on one object; the second search starts from the first one's noise floor
+    from test_oracle_golden import _cox_cases
+    import pyoracle as po
+    O = po.Oracle()
+    x, thr, nf0, r = _cox_cases(golden)[1]
+    fin = str(tmp_path / "cox1.f32")
+    x.tofile(fin)
+    t = subprocess.check_output([exe, "6", "2", fin, repr(thr), "0", "x", "2"]).decode().split("\n")
+    assert int(t[0]) == 8064
+    a, nfa = O.cox_search(x, thr, 0.0)
+    b, _ = O.cox_search(x, thr, nfa)
+    for line, exp in ((t[1].split(), a), (t[2].split(), b)):
+        assert int(line[0]) == int(exp[0]) == 1 and int(line[1]) == int(exp[1]) and np.float32(float(line[2])) == exp[2]

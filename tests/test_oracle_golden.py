@@ -148,6 +148,39 @@ def test_chirp_sync_oracle_matches_reference_golden(oracle, golden):
         assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (len(x), out, r)
 
 
+def _cox_cases(golden):
+    """Rebuilds the Schmidl-Cox fixture's buffers from its recipe (reference TX audio from the fixture + seeded numpy
+    noise); skips if this numpy no longer reproduces them."""
+    import gen_golden
+    g = golden("cox_sync")
+    out = []
+    for i, case in enumerate(g["cases"]):
+        x, crc = gen_golden.cox_buffer(g["tx"], case, i)
+        if crc != int(g["buffer_crc"][i]):
+            pytest.skip("numpy no longer reproduces the recorded noise stream; regenerate with oracle/gen_golden.py")
+        out.append((x, float(case[4]), float(case[5]), g["results"][i]))
+    return out
+
+
+def test_cox_search_oracle_matches_reference_golden(oracle, golden):
+    """OFDMDemodulator::searchForSync as OFDMNvisWaveform::detectSync calls it (Schmidl-Cox metric on the FFT-Hilbert
+    analytic signal, plateau rule, LTS refinement incl. rejected candidates, coarse CFO, noise-floor tracker):
+    found / position / CFO / noise floor bit for bit; LTS passband templates of two configurations."""
+    import pyoracle as po
+    g = golden("cox_sync")
+    for name, mod, rate in (("qam16_r12", po.QAM16, po.R1_2), ("dqpsk_r14", po.DQPSK, po.R1_4)):
+        tI, tQ = oracle.cox_lts_template(mod, rate)
+        assert np.array_equal(tI.view(np.uint32), g[f"tI_{name}"].view(np.uint32))
+        assert np.array_equal(tQ.view(np.uint32), g[f"tQ_{name}"].view(np.uint32))
+    n_found = 0
+    for i, (x, thr, nf0, r) in enumerate(_cox_cases(golden)):
+        out, nf = oracle.cox_search(x, thr, nf0)
+        got = np.concatenate([out, [nf]]).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), (i, got, r)
+        n_found += int(r[0])
+    assert n_found >= 12
+
+
 def test_mcdpsk_oracle_matches_reference_golden(oracle, golden):
     """MultiCarrierDPSK modulator (by checksum) and demodulator chain incl. Hilbert CFO correction, spreading
     2x/4x, DBPSK reliability weights and trailing-silence trimming: LLRs and fading indices bit for bit."""
