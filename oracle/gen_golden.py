@@ -93,15 +93,25 @@ def cox_fixture(R):
         tI, tQ = R.cox_lts_template(mod, rate)
         rec[f"tI_{name}"], rec[f"tQ_{name}"] = tI, tQ
         rec[f"preamble_{name}"] = R.cox_transmit(None, mod, rate)
-    coded = rng.integers(0, 256, 324, dtype=np.uint8)
+    payload = rng.integers(0, 256, 141, dtype=np.uint8)
+    _, info, coded, bps = R.tx_frame(po.QAM16, po.R1_2, payload, 77)
     tx = R.cox_transmit(coded)
-    rec["tx"] = tx
-    crcs, res = [], []
+    rec["tx"], rec["info"] = tx, info[:160]
+    crcs, res, e2e_idx, e2e_llr, e2e_dec = [], [], [], [], []
     for i, case in enumerate(COX_CASES):
         x, crc = cox_buffer(tx, case, i)
         out, nf = R.cox_search(x, float(case[4]), float(case[5]))
         crcs.append(crc)
         res.append(np.concatenate([out, [nf]]).astype(np.float32))
+        # end to end (detectSync -> process -> getSoftBits -> decodeFixedFrame) where a whole frame follows the sync point
+        if out[0] and int(out[1]) + 18432 <= len(x) and float(case[5]) == 0.0:
+            o3, llr, _ = R.cox_rx(x, float(case[4]))
+            assert np.array_equal(o3, out) and len(llr) >= 2632
+            d, ok = R.decode_fixed_frame(llr[:2632], po.R1_2, True, bps)
+            e2e_idx.append(i); e2e_llr.append(llr[:2632]); e2e_dec.append(np.concatenate([ok, d[:160]]))
+    rec["e2e_case"] = np.array(e2e_idx, np.int32)
+    rec["e2e_llr"] = np.stack(e2e_llr)
+    rec["e2e_dec"] = np.stack(e2e_dec)      # [4 ok flags | 160 info bytes]
     rec["buffer_crc"] = np.array(crcs, np.uint32)
     rec["results"] = np.stack(res)
     return rec

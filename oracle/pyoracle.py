@@ -268,6 +268,7 @@ class Ref:
         L.ref_cox_search.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, _f, _f]
         L.ref_cox_transmit.argtypes = [C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
         L.ref_cox_lts_template.argtypes = [C.c_int, C.c_int, _f, _f]
+        L.ref_cox_rx.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, _f, _f, C.c_int, _f]
         L.ref_quiet()
 
     def cox_search(self, samples, threshold=0.8, noise_floor=0.0, mod=QAM16, rate=R1_2):
@@ -284,6 +285,13 @@ class Ref:
         n = self.lib.ref_cox_transmit(mod, rate, up(coded), len(coded), fp(out), len(out))
         assert n > 0, n
         return out[:n].copy()
+
+    def cox_rx(self, samples, threshold=0.8, mod=QAM16, rate=R1_2):
+        """OFDM-COX detectSync + process -> (float32[3] {found, position, cfo}, soft bits, float32[2] {snr_db, cfo after})"""
+        x = np.ascontiguousarray(samples, np.float32)
+        out, llr, aux = np.zeros(3, np.float32), np.zeros(8192, np.float32), np.zeros(2, np.float32)
+        n = self.lib.ref_cox_rx(mod, rate, fp(x), len(x), threshold, fp(out), fp(llr), len(llr), fp(aux))
+        return out, llr[:abs(n)].copy(), aux
 
     def cox_lts_template(self, mod=QAM16, rate=R1_2):
         tI, tQ = np.zeros(1152, np.float32), np.zeros(1152, np.float32)

@@ -305,6 +305,23 @@ int ref_cox_lts_template(int mod, int rate, float* tI, float* tQ) {
     std::memcpy(tQ, im.lts_passband_Q.data(), n * sizeof(float));
     return n;
 }
+// OFDM-COX end to end on one capture buffer: detectSync (Schmidl-Cox) -> process(samples from the LTS on) -> soft bits
+// (ofdm_cox_waveform.cpp:125-214).  out3 = {found, first-LTS position, cfo}; returns the soft-bit count (0 if not found).
+int ref_cox_rx(int mod, int rate, const float* samples, int n, float thr, float* out3, float* llr_out, int max_llr, float* aux2) {
+    ref_quiet();
+    OFDMNvisWaveform rx(named_config(mod, rate));
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    SyncResult r;
+    bool ok = rx.detectSync(SampleSpan(samples, n), r, thr);
+    out3[0] = ok ? 1.0f : 0.0f; out3[1] = ok ? static_cast<float>(r.start_sample) : 0.0f; out3[2] = ok ? r.cfo_hz : 0.0f;
+    if (!ok) return 0;
+    bool ready = rx.process(SampleSpan(samples + r.start_sample, n - r.start_sample));
+    std::vector<float> soft = rx.getSoftBits();
+    int m = static_cast<int>(soft.size());
+    std::memcpy(llr_out, soft.data(), std::min(m, max_llr) * sizeof(float));
+    if (aux2) { aux2[0] = rx.estimatedSNR(); aux2[1] = rx.estimatedCFO(); }
+    return ready ? m : -m;
+}
 // Dual chirp (chirp_sync.hpp:352-512); out = {success, up_start, down_start, cfo_hz, up_corr, down_corr}
 int ref_chirp_detect(const float* samples, int n, float thr, float* out6) {
     ref_quiet();

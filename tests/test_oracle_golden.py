@@ -179,6 +179,17 @@ def test_cox_search_oracle_matches_reference_golden(oracle, golden):
         assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), (i, got, r)
         n_found += int(r[0])
     assert n_found >= 12
+    # OFDM-COX end to end: detectSync -> process(from the LTS on) -> soft bits -> decodeFixedFrame, incl. false locks
+    cases = _cox_cases(golden)
+    for k, ci in enumerate(g["e2e_case"]):
+        x, thr, nf0, r = cases[int(ci)]
+        pos = int(r[1])
+        llr, _ = oracle.rx_process(po.QAM16, po.R1_2, x[pos:pos + 18432], float(r[2]), pos)
+        assert np.array_equal(llr[:2632].view(np.uint32), g["e2e_llr"][k].view(np.uint32)), ci
+        d, ok, _, _ = oracle.decode_fixed_frame(llr[:2632], po.R1_2, True, 188, flags=7)
+        assert np.array_equal(ok, g["e2e_dec"][k][:4]), ci
+        if ok.all():
+            assert np.array_equal(d[:160], g["e2e_dec"][k][4:]) and np.array_equal(d[:160], g["info"])
 
 
 def test_mcdpsk_oracle_matches_reference_golden(oracle, golden):

@@ -52,6 +52,18 @@ def main():
     x = torch.randn((n, 21000), device="cuda") * 0.1
     t = timed(lambda: e.sync_lts(x, None, 0.5))
     res["lts"] = {"buffers": n, "samples": 21000, "ms": round(t * 1e3, 2), "spans_per_s": round(n / t)}
+    # Schmidl-Cox (OFDM-COX searchForSync): 8064-sample preamble at a random offset of 30000-sample noisy buffers
+    pre = torch.from_numpy(e.cox_preamble()).cuda()
+    n = 2048
+    buf = torch.randn((n, 30000), device="cuda") * 0.02
+    offs = rng.integers(0, 15000, n)
+    idx = torch.from_numpy(offs).cuda()[:, None] + torch.arange(len(pre), device="cuda")[None, :]
+    buf.scatter_add_(1, idx, pre[None, :].expand(n, -1))
+    t = timed(lambda: e.sync_cox(buf, 0.8))
+    r = e.sync_cox(buf, 0.8)
+    exact = int((r["start_sample"] == offs + 5 * 1152).sum())
+    res["cox"] = {"buffers": n, "samples": 30000, "ms": round(t * 1e3, 2), "buffers_per_s": round(n / t), "found": int(r["found"].sum()),
+                  "first_lts_exact": exact, "metric_offsets_per_s": round(n * ((30000 - 6913) // 8 + 1) / t)}
     # MC-DPSK: C1 shape, 10 carriers DBPSK, one codeword (74 symbols)
     n = 8000
     x = torch.randn((n, 74 * 512), device="cuda") * 0.1
