@@ -39,36 +39,42 @@ namespace ria {
 // structure differs.
 struct ShapeR12 {   // R1/2: m = 324, k = 324
     static constexpr int NR = 6, NC = 6;
+    static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 2, 1}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 5, 4, 2, 1, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {5, 4, 4, 4, 4, 4}; return t[r]; }
 };
 struct ShapeR13 {   // R1/3 entry of the rate table: same (324,324) parameters, H seeded differently
     static constexpr int NR = 6, NC = 6;
+    static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 3, 3, 1}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 5, 3, 3, 1, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {6, 4, 4, 4, 4, 4}; return t[r]; }
 };
 struct ShapeR14 {   // m = 486, k = 162
     static constexpr int NR = 8, NC = 3;
+    static constexpr int kCascadeWaves = 2;   // waves/SIMD the cascade kernel is held to (its register budget)
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 5, 4, 3, 2, 2}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 2, 2, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {13, 12, 12}; return t[r]; }
 };
 struct ShapeR23 {   // m = 216, k = 432
     static constexpr int NR = 4, NC = 7;
+    static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6, 4}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 3}; return t[r]; }
 };
 struct ShapeR34 {   // m = 162, k = 486 (161 information columns have no edge at all)
     static constexpr int NR = 3, NC = 8;
+    static constexpr int kCascadeWaves = 4;   // waves/SIMD the cascade kernel is held to (its register budget)
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 0, 0}; return t[r]; }
 };
 struct ShapeR56 {   // m = 108, k = 540
     static constexpr int NR = 2, NC = 9;
+    static constexpr int kCascadeWaves = 5;   // waves/SIMD the cascade kernel is held to (its register budget)
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 0, 0, 0, 0, 0}; return t[r]; }
@@ -367,6 +373,11 @@ __device__ inline void fast_pack(const FastState<S>& st, const FastCode& c, unsi
 }
 
 // ------------------------------------------------------------------------------------------------ args
+// Cascade result slot of one entry.  A wave whose attempt succeeded AND lowered best[e] takes the lock, checks that it
+// still is the best, and stores its bytes; the overall first successful attempt always passes both tests, and every
+// store happens under the lock, so after the kernel the slot holds exactly that attempt's result.
+struct CascadeWin { unsigned int lock; unsigned int iters; uint8_t bytes[72]; };   // 80 bytes
+
 struct DecodeCtl {          // zeroed by hipMemsetAsync before every decode call
     unsigned int n_entries; // codewords that need the cascade
     unsigned int next_unit; // cascade work queue head
@@ -400,6 +411,7 @@ struct FastDecodeArgs {
     unsigned int* list1;     // [4*n_frames]  frame*4 + cw needing factors 1..4
     CwResult* res;           // [4*n_frames]
     uint8_t* res_bytes;      // [4*n_frames][5][bytes_per_cw]
+    CascadeWin* win;         // [4*n_frames]  result of the best successful cascade attempt so far, per entry
 };
 
 constexpr float kIdleRowLlr = 1e30f;   // idle row lanes: a parity bit that is certainly 0 keeps their syndrome term 0
@@ -506,6 +518,7 @@ __global__ void fast_chain_kernel(FastDecodeArgs A) {
                 unsigned e = atomicAdd(&A.ctl->n_entries, 1u);
                 A.entries[e] = fc;
                 A.best[e] = 0xFFFFFFFFu;
+                A.win[e].lock = 0u;
             }
         }
         uint8_t* out = A.info_out + static_cast<size_t>(fc) * bpc;
@@ -564,7 +577,7 @@ __device__ inline uint32_t fast_hash16(const float* fl, const uint16_t* gather, 
 // ------------------------------------------------------------------------------------------------ kernel D2
 // persistent single-wave workgroups; unit u = attempt-major (a = u / n_entries, e = u % n_entries)
 template <class S>
-__global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeWaves))) void fast_cascade_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FastCode& c = A.c;
     const int lane = threadIdx.x;
@@ -593,47 +606,44 @@ __global__ __launch_bounds__(64) void fast_cascade_kernel(FastDecodeArgs A) {
         uint32_t h = fast_hash16(A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
-        (void)fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
-        if (ok && lane == 0) atomicMin(&A.best[e], a);
+        const int it = fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
+        if (ok) {
+            unsigned int prev = 0;
+            if (lane == 0) prev = atomicMin(&A.best[e], a);
+            prev = __shfl(prev, 0);
+            if (a < prev) {   // best so far: publish under the entry's lock (held for one 40..68-byte store)
+                CascadeWin* w = A.win + e;
+                if (lane == 0) while (atomicCAS(&w->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                __threadfence();
+                unsigned int cur = __hip_atomic_load(&A.best[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur = __shfl(cur, 0);
+                if (cur == a) {
+                    fast_pack(st, c, smem, w->bytes, c.bytes_per_cw, lane);
+                    if (lane == 0) w->iters = static_cast<unsigned int>(it);
+                }
+                __threadfence();
+                if (lane == 0) atomicExch(&w->lock, 0u);
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ kernel D3
-// one wave per cascade entry: re-run the winning attempt (deterministic) and publish its bytes
-template <class S>
-__global__ __launch_bounds__(64) void fast_finalize_kernel(FastDecodeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const FastCode& c = A.c;
-    const int lane = threadIdx.x;
+// one thread per cascade entry: publish the winning attempt's bytes (stored by the cascade under the entry's lock)
+__global__ __launch_bounds__(256) void fast_finalize_kernel(FastDecodeArgs A) {
     const unsigned int n_entries = A.ctl->n_entries;
-    float* msg = reinterpret_cast<float*>(smem);
-    for (unsigned int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+    const int bpc = A.c.bytes_per_cw;
+    for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
         const unsigned int fc = A.entries[e], frame = fc >> 2, cw = fc & 3;
         const unsigned int a = A.best[e];
         ria_decode_status* s = A.status + frame;
-        if (a >= 34u) {
-            if (lane == 0) s->attempts[cw] = static_cast<uint8_t>(s->attempts[cw] + 34);
-            continue;
-        }
-        FastState<S> st;
-        fast_load_tables(st, c, smem, lane);
-        fast_gather_llr(st, c, A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, cw, lane);
-        float bi[S::NC], bp[S::NR];
-#pragma unroll
-        for (int r = 0; r < S::NC; ++r) bi[r] = st.li[r];
-#pragma unroll
-        for (int r = 0; r < S::NR; ++r) bp[r] = st.lp[r];
-        uint32_t h = fast_hash16(A.llr + static_cast<size_t>(frame) * A.llr_stride, A.gather, cw, lane);
-        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
-        bool ok;
-        int it = fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
-        fast_pack(st, c, smem, A.info_out + (static_cast<size_t>(frame) * 4 + cw) * c.bytes_per_cw,
-                  c.bytes_per_cw, lane);
-        if (lane == 0) {
-            s->cw_ok[cw] = ok ? 1 : 0;  // ok is true by construction
-            s->iterations[cw] = static_cast<uint16_t>(it);
-            s->attempts[cw] = static_cast<uint8_t>(s->attempts[cw] + a + 1);
-        }
+        if (a >= 34u) { s->attempts[cw] = static_cast<uint8_t>(s->attempts[cw] + 34); continue; }
+        const CascadeWin* w = A.win + e;
+        uint8_t* out = A.info_out + (static_cast<size_t>(frame) * 4 + cw) * bpc;
+        for (int b = 0; b < bpc; ++b) out[b] = w->bytes[b];
+        s->cw_ok[cw] = 1;
+        s->iterations[cw] = static_cast<uint16_t>(w->iters);
+        s->attempts[cw] = static_cast<uint8_t>(s->attempts[cw] + a + 1);
     }
 }
 

@@ -69,6 +69,7 @@ struct ria_gpu {
     unsigned int* d_list1 = nullptr;      // [4 * ws_frames]
     CwResult* d_res = nullptr;            // [4 * ws_frames]
     uint8_t* d_res_bytes = nullptr;       // [4 * ws_frames][5][bytes_per_cw]
+    CascadeWin* d_win = nullptr;          // [4 * ws_frames]
     int ws_frames = 0;
     // CRC-recovery staging (device + pinned host mirrors), sized for ws_frames
     unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr; unsigned int* d_stage2 = nullptr;
@@ -145,9 +146,9 @@ static bool shape_fits(int rate, const CoreTables& t, int* wave_lds) {
 }
 static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     if (n_frames <= h->ws_frames && h->d_ctl) return hipSuccess;
-    for (void* p_ : {(void*)h->d_entries, (void*)h->d_best, (void*)h->d_list1, (void*)h->d_res, (void*)h->d_res_bytes})
+    for (void* p_ : {(void*)h->d_entries, (void*)h->d_best, (void*)h->d_list1, (void*)h->d_res, (void*)h->d_res_bytes, (void*)h->d_win})
         if (p_) (void)hipFree(p_);
-    h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr;
+    h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr; h->d_win = nullptr;
     hipError_t e;
     if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), kMaxParts * sizeof(DecodeCtl))) != hipSuccess) return e;   // one per stream slot
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_entries), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
@@ -155,6 +156,7 @@ static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_list1), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_res), static_cast<size_t>(n_frames) * 4 * sizeof(CwResult))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_res_bytes), static_cast<size_t>(n_frames) * 4 * kNumFactors * h->geo.bytes_per_codeword)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_win), static_cast<size_t>(n_frames) * 4 * sizeof(CascadeWin))) != hipSuccess) return e;
     h->ws_frames = n_frames;
     return hipSuccess;
 }
@@ -164,7 +166,6 @@ static void set_fast_attributes(int rate, int wb) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_primary_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_finalize_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(recovery_fill_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
     });
@@ -367,7 +368,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
                     h->d_crc_bit, h->d_crc_init, h->d_zc_ref, h->d_ch_tw, h->d_ch_tmpl, h->d_ch_tmpl_fft, h->d_ch_w1, h->d_ch_w2, h->d_ch_mag, h->d_ch_cum, h->d_ch_st, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
-                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes,
+                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes, h->d_win,
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& st_ : h->aux_stream) if (st_) (void)hipStreamDestroy(st_);
@@ -547,6 +548,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.list1 = h->d_list1 + o4;
     A.res = h->d_res + o4;
     A.res_bytes = h->d_res_bytes + o4 * kNumFactors * h->geo.bytes_per_codeword;
+    A.win = h->d_win + o4;
     if ((e = hipMemsetAsync(A.ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const int wb = h->wave_lds;
@@ -572,7 +574,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
             // persistent waves over the device-side work list; sized to fill the chip (256 CUs x 12)
             hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(3072), dim3(64), wb, s, A);
             stage("cascade");
-            hipLaunchKernelGGL(fast_finalize_kernel<S>, dim3(2048), dim3(64), wb, s, A);
+            hipLaunchKernelGGL(fast_finalize_kernel, dim3(std::min((4 * n_frames + 255) / 256, 1024)), dim3(256), 0, s, A);
             stage("finalize");
         }
     });
