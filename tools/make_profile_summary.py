@@ -56,7 +56,7 @@ L = [f"# {tag} — bench, kernel trace and PMC summaries\n",
      "Commands (MI355X box, repo root, after `cd /tmp && export TMPDIR=/tmp`):\n",
      f"* `python bench.py` -> `{tag}_bench.json`",
      f"* `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` -> `{tag}_bench_kernel_stats.csv`",
-     f"* `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1`, same with `WRITE_SIZE` (separate passes) -> `{tag}_hbm_traffic_pmc.json` (bytes per launch = per 12 500-frame half of a 25 000-frame step since the batch runs as two halves on two streams; FETCH_SIZE x 2 for gfx950; Infinity-Cache hits are counted)",
+     f"* `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1`, same with `WRITE_SIZE` (separate passes) -> `{tag}_hbm_traffic_pmc.json` (both passes with `RIA_NO_SPLIT=1`, so one launch = one whole 25 000-frame step, the unit `bench.py`'s roofline uses; FETCH_SIZE x 2 for gfx950; Infinity-Cache hits are counted)",
      f"* `rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py ...` -> `{tag}_sq_utilisation_pmc.json`\n",
      f"Bench line: **{bench['value']:.0f} frames/s** on 1 MI355X ({bench['ms_per_step']} ms per 25 000-frame step); reference CPU path on the same box: {bench['cpu_baseline']['value']} frames/s on {bench['cpu_baseline']['cores']} threads ({bench['cpu_baseline']['kind']}).\n",
      "| kernel | calls | avg ms | % of GPU time |", "|---|---|---|---|"]
