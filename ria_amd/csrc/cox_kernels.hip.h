@@ -13,7 +13,8 @@
 // replayed over the tables by one lane:
 //   cox_prepare_kernel  one LANE per 8-sample offset: the 1024-term left-to-right DC sum, and on the 64-sample
 //                       grid the 144-term energy of hasMinimumEnergy.
-//   cox_metric_kernel   one WAVE per 8-sample offset: DC removal, forward FFT-1024 (the reference's radix-2 DIT
+//   cox_metric_kernel   (two passes: the 64-sample grid first, then only the plateau offsets around grid points above the
+//                       threshold) one WAVE per 8-sample offset: DC removal, forward FFT-1024 (the reference's radix-2 DIT
 //                       order, as in the demodulator kernel), Hilbert mask, inverse FFT, the 512 conjugate
 //                       products by all lanes and the four 512-term ordered sums (P.re, P.im, R1, R2) by four
 //                       lanes, normalised metric.
@@ -139,11 +140,25 @@ __device__ __forceinline__ float cox_chain512(const float* f) {   // left-to-rig
     return acc;
 }
 
+// PHASE 0: the offsets of the 64-sample search grid (every 8th table entry).  PHASE 1: the other offsets, but only
+// those a plateau scan can read: o in [i, i + 300] for a grid point i whose metric exceeds the threshold
+// (demodulator.cpp:1494-1509) - a superset of what the sequential walk touches, since the energy gate is ignored.
+template <int PHASE>
 __global__ __launch_bounds__(256) void cox_metric_kernel(CoxArgs A) {
     __shared__ __attribute__((aligned(16))) float2 smem[4 * kFftBufFloats2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + wave;
+    const int kk = blockIdx.x * 4 + wave;
+    const int k = PHASE == 0 ? 8 * kk : kk;
     if (k >= A.nM) return;
+    if (PHASE == 1) {
+        if ((k & 7) == 0) return;
+        const float* Mg = A.metric + static_cast<long long>(blockIdx.y) * A.nM;
+        const int o = 8 * k, search_end = A.buf_len - kCoxTotal - kCoxWindow;
+        bool needed = false;
+        for (int i = (o >> 6) << 6; i >= 0 && o - i <= 300; i -= 64)
+            if (i < search_end && Mg[i >> 3] > A.threshold) needed = true;
+        if (!needed) return;
+    }
     const int b = blockIdx.y;
     float2* buf = smem + wave * kFftBufFloats2;
     const float* d = A.samples + static_cast<long long>(b) * A.stride + 8 * k + kCoxCp;

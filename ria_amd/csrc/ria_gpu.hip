@@ -1013,7 +1013,8 @@ int ria_gpu_sync_cox_batch(ria_gpu_handle h, const float* samples_dev, int64_t s
         A.nM = nM; A.nE = nE; A.out = out_dev + first;
         if (nM > 0) {
             hipLaunchKernelGGL(cox_prepare_kernel, dim3((nM + 255) / 256, nb), dim3(256), 0, s, A);
-            hipLaunchKernelGGL(cox_metric_kernel, dim3((nM + 3) / 4, nb), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(cox_metric_kernel<0>, dim3(((nM + 7) / 8 + 3) / 4, nb), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(cox_metric_kernel<1>, dim3((nM + 3) / 4, nb), dim3(256), 0, s, A);
         }
         hipLaunchKernelGGL(cox_scan_kernel, dim3(nb), dim3(1024), 0, s, A);
     }
