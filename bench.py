@@ -106,15 +106,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RIA_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend - a rehearsal of the N > 1 control flow on a
+    # one-GPU box (the driver's real runs use one GPU per rank over RCCL)
+    rehearse = os.environ.get("RIA_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    cdev = torch.device("cpu") if rehearse else dev      # where the few-byte collectives live
 
     # seed broadcast (the only data-path-adjacent collective: tens of bytes over xGMI)
-    seed_t = torch.tensor([args.seed], dtype=torch.int64, device=dev)
+    seed_t = torch.tensor([args.seed], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.broadcast(seed_t, 0)
     seed = int(seed_t.item())
@@ -153,8 +162,8 @@ def main():
     st = e.decode_status(out[1])
     frames_ok = int((st["cw_ok"].all(axis=1) & st["frame_valid"].astype(bool)).sum())
     bytes_ok = int((out[0] == infos[-1]).all(dim=1).sum().item())
-    cnt = torch.tensor([B * args.steps, frames_ok, bytes_ok, int(st["iterations"].sum())], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([B * args.steps, frames_ok, bytes_ok, int(st["iterations"].sum())], dtype=torch.int64, device=cdev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

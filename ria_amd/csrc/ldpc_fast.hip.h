@@ -412,7 +412,17 @@ struct FastDecodeArgs {
     CwResult* res;           // [4*n_frames]
     uint8_t* res_bytes;      // [4*n_frames][5][bytes_per_cw]
     CascadeWin* win;         // [4*n_frames]  result of the best successful cascade attempt so far, per entry
+    float* staged;           // [4*n_frames][kStageFloats]  de-interleaved decoder input of list1 entry i, in register order
+    unsigned int* l1idx;     // [4*n_frames]  codeword -> its list1 index (valid for listed codewords only)
+    unsigned int* l1hash;    // [4*n_frames]  list1 entry -> hash of its first 16 soft bits (seed of the perturbation RNG)
 };
+
+// A codeword that needs more than its first decode is decoded up to 4 + 34 more times.  Its soft bits are gathered
+// from the frame's interleaved stream once (fast_stage_kernel) into the order the decoder's registers want them
+// (value r of lane l at [r*64 + l], information part then parity part), so every later unit is (NC+NR) coalesced
+// loads instead of a walk over the whole 10 KB frame.
+constexpr int kStageFloats = 12 * 64;
+constexpr int kStageFrameFloats = 2688;   // largest interleaved frame: 2592 coded bits rounded up to whole symbols (D8PSK: 2650)
 
 constexpr float kIdleRowLlr = 1e30f;   // idle row lanes: a parity bit that is certainly 0 keeps their syndrome term 0
 
@@ -432,11 +442,23 @@ __device__ inline void fast_gather_llr(FastState<S>& st, const FastCode& c, cons
     }
 }
 
-// decode codeword `fc` (= frame*4 + cw) with factor index f and record the result
 template <class S>
-__device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, unsigned char* lds, unsigned fc, int f, int lane) {
+__device__ inline void fast_load_staged(FastState<S>& st, const float* __restrict__ src, int lane) {
+    static_assert((S::NC + S::NR) * 64 <= kStageFloats, "stage slot too small");
+#pragma unroll
+    for (int r = 0; r < S::NC; ++r) st.li[r] = src[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < S::NR; ++r) st.lp[r] = src[(S::NC + r) * 64 + lane];
+}
+
+// decode codeword `fc` (= frame*4 + cw) with factor index f and record the result; staged != nullptr: the
+// codeword's de-interleaved input (fast_stage_kernel) instead of the gather from the frame
+template <class S>
+__device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, unsigned char* lds, unsigned fc, int f, int lane,
+                                 const float* staged = nullptr) {
     const FastCode& c = A.c;
-    fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
+    if (staged) fast_load_staged(st, staged, lane);
+    else fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
     bool ok;
     int it = fast_decode(st, c, lds, kFactors[f], c.max_iter, lane, &ok);
     if (ok) fast_pack(st, c, lds, A.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw,
@@ -472,7 +494,57 @@ __global__ void fast_mark_kernel(FastDecodeArgs A) {
     for (int cw = 0; cw < 4; ++cw) {
         unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
         failed = failed || A.res[fc].state[0] != 2;
-        if (failed) A.list1[atomicAdd(&A.ctl->n_list1, 1u)] = fc;
+        if (failed) {
+            const unsigned i = atomicAdd(&A.ctl->n_list1, 1u);
+            A.list1[i] = fc;
+            A.l1idx[fc] = i;
+        }
+    }
+}
+
+// hash of the bit patterns of the codeword's first 16 LLRs (frame_v2.cpp:1391-1396)
+__device__ inline uint32_t fast_hash16(const float* fl, const uint16_t* gather, int cw, int lane) {
+    const uint32_t mine = f2u(fl[gather[cw * 648 + (lane & 15)]]);
+    uint32_t h = 0;
+    for (int j = 0; j < 16; ++j) {
+        uint32_t u = __shfl(mine, j);
+        h ^= u + 0x9e3779b9u + (h << 6) + (h >> 2);
+    }
+    return h;
+}
+
+// one workgroup per list1 entry: the frame's soft bits come in as coalesced rows into LDS (one pass over the 10 KB
+// frame: scattered 4-byte misses to the same line are not merged on their way to HBM), the codeword is gathered from
+// LDS in register order (see kStageFloats), and the perturbation seed hash of its first 16 soft bits is kept
+template <class S>
+__global__ __launch_bounds__(256) void fast_stage_kernel(FastDecodeArgs A) {
+    __shared__ float fr[kStageFrameFloats];
+    const FastCode& c = A.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned n = A.ctl->n_list1;
+    const int nfl = A.llr_stride < kStageFrameFloats ? A.llr_stride : kStageFrameFloats;
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const unsigned fc = A.list1[i], cw = fc & 3u;
+        const float* fl = A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride;
+        __syncthreads();
+        for (int q = tid; q < nfl; q += 256) fr[q] = fl[q];
+        __syncthreads();
+        float* dst = A.staged + static_cast<size_t>(i) * kStageFloats;
+        for (int r = wave; r < S::NC + S::NR; r += 4) {
+            float v;
+            if (r < S::NC) {
+                const uint32_t j = c.col_at[lane + 64 * r];
+                v = (j != 0xFFFFu) ? llr_canon(fr[A.gather[cw * 648 + j]]) : 0.0f;
+            } else {
+                const uint32_t k = c.check_at[lane + 64 * (r - S::NC)];
+                v = (k != 0xFFFFu) ? llr_canon(fr[A.gather[cw * 648 + c.k + k]]) : kIdleRowLlr;
+            }
+            dst[r * 64 + lane] = v;
+        }
+        if (wave == 0) {
+            const uint32_t h = fast_hash16(fr, A.gather, cw, lane);
+            if (lane == 0) A.l1hash[i] = h;
+        }
     }
 }
 
@@ -489,7 +561,7 @@ __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
     for (unsigned u = blockIdx.x; u < total; u += gridDim.x)
-        fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane);
+        fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane, A.staged + static_cast<size_t>(u >> 2) * kStageFloats);
 }
 
 // ------------------------------------------------------------------------------------------------ chain
@@ -563,17 +635,6 @@ __device__ inline float fast_perturb(FastState<S>& st, const FastCode& c, const 
     return factor;
 }
 
-// hash of the bit patterns of the codeword's first 16 LLRs (frame_v2.cpp:1391-1396)
-__device__ inline uint32_t fast_hash16(const float* fl, const uint16_t* gather, int cw, int lane) {
-    const uint32_t mine = f2u(fl[gather[cw * 648 + (lane & 15)]]);
-    uint32_t h = 0;
-    for (int j = 0; j < 16; ++j) {
-        uint32_t u = __shfl(mine, j);
-        h ^= u + 0x9e3779b9u + (h << 6) + (h >> 2);
-    }
-    return h;
-}
-
 // ------------------------------------------------------------------------------------------------ kernel D2
 // persistent single-wave workgroups; unit u = attempt-major (a = u / n_entries, e = u % n_entries)
 template <class S>
@@ -597,13 +658,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
         b = __shfl(b, 0);
         if (b < a) continue;  // an earlier attempt already succeeded: this one can never be chosen
         const unsigned int fc = A.entries[e];
-        fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
+        const unsigned int li = A.l1idx[fc];
+        fast_load_staged(st, A.staged + static_cast<size_t>(li) * kStageFloats, lane);
         float bi[S::NC], bp[S::NR];
 #pragma unroll
         for (int r = 0; r < S::NC; ++r) bi[r] = st.li[r];
 #pragma unroll
         for (int r = 0; r < S::NR; ++r) bp[r] = st.lp[r];
-        uint32_t h = fast_hash16(A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
+        const uint32_t h = A.l1hash[li];
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
         const int it = fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);

@@ -70,6 +70,9 @@ struct ria_gpu {
     CwResult* d_res = nullptr;            // [4 * ws_frames]
     uint8_t* d_res_bytes = nullptr;       // [4 * ws_frames][5][bytes_per_cw]
     CascadeWin* d_win = nullptr;          // [4 * ws_frames]
+    float* d_staged = nullptr;            // [4 * ws_frames][kStageFloats]
+    unsigned int* d_l1idx = nullptr;      // [4 * ws_frames]
+    unsigned int* d_l1hash = nullptr;     // [4 * ws_frames]
     int ws_frames = 0;
     // CRC-recovery staging (device + pinned host mirrors), sized for ws_frames
     unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr; unsigned int* d_stage2 = nullptr;
@@ -146,9 +149,9 @@ static bool shape_fits(int rate, const CoreTables& t, int* wave_lds) {
 }
 static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     if (n_frames <= h->ws_frames && h->d_ctl) return hipSuccess;
-    for (void* p_ : {(void*)h->d_entries, (void*)h->d_best, (void*)h->d_list1, (void*)h->d_res, (void*)h->d_res_bytes, (void*)h->d_win})
+    for (void* p_ : {(void*)h->d_entries, (void*)h->d_best, (void*)h->d_list1, (void*)h->d_res, (void*)h->d_res_bytes, (void*)h->d_win, (void*)h->d_staged, (void*)h->d_l1idx, (void*)h->d_l1hash})
         if (p_) (void)hipFree(p_);
-    h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr; h->d_win = nullptr;
+    h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr; h->d_win = nullptr; h->d_staged = nullptr; h->d_l1idx = nullptr; h->d_l1hash = nullptr;
     hipError_t e;
     if (!h->d_ctl && (e = hipMalloc(reinterpret_cast<void**>(&h->d_ctl), kMaxParts * sizeof(DecodeCtl))) != hipSuccess) return e;   // one per stream slot
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_entries), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
@@ -157,6 +160,9 @@ static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_res), static_cast<size_t>(n_frames) * 4 * sizeof(CwResult))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_res_bytes), static_cast<size_t>(n_frames) * 4 * kNumFactors * h->geo.bytes_per_codeword)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_win), static_cast<size_t>(n_frames) * 4 * sizeof(CascadeWin))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_staged), static_cast<size_t>(n_frames) * 4 * kStageFloats * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_l1idx), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_l1hash), static_cast<size_t>(n_frames) * 4 * sizeof(unsigned))) != hipSuccess) return e;
     h->ws_frames = n_frames;
     return hipSuccess;
 }
@@ -368,7 +374,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_row_deg, h->d_row_var, h->d_col_deg, h->d_col_slot, h->d_gather, h->d_gather_nochan,
                     h->d_crc_bit, h->d_crc_init, h->d_zc_ref, h->d_ch_tw, h->d_ch_tmpl, h->d_ch_tmpl_fft, h->d_ch_w1, h->d_ch_w2, h->d_ch_mag, h->d_ch_cum, h->d_ch_st, h->d_twiddle, h->d_nco, h->d_demod_const, h->d_tx_const, h->d_llr_ws,
-                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes, h->d_win,
+                    h->d_ctl, h->d_entries, h->d_best, h->d_list1, h->d_res, h->d_res_bytes, h->d_win, h->d_staged, h->d_l1idx, h->d_l1hash,
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& st_ : h->aux_stream) if (st_) (void)hipStreamDestroy(st_);
@@ -549,6 +555,9 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.res = h->d_res + o4;
     A.res_bytes = h->d_res_bytes + o4 * kNumFactors * h->geo.bytes_per_codeword;
     A.win = h->d_win + o4;
+    A.staged = h->d_staged + o4 * kStageFloats;
+    A.l1idx = h->d_l1idx + o4;
+    A.l1hash = h->d_l1hash + o4;
     if ((e = hipMemsetAsync(A.ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const int wb = h->wave_lds;
@@ -565,6 +574,10 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
         stage("primary");
         hipLaunchKernelGGL(fast_mark_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
         stage("mark");
+        if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB)) {
+            hipLaunchKernelGGL(fast_stage_kernel<S>, dim3(std::min(4 * n_frames, 8192)), dim3(256), 0, s, A);
+            stage("stage");
+        }
         if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB))
             hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, 16384)), dim3(64), wb, s, A);
         stage("phase0");
