@@ -409,6 +409,44 @@ def test_cox_sync_matches_oracle_batch(oracle, golden):
         assert n_found >= n // 3, n_found
 
 
+def test_cox_sync_vs_the_reference_library(golden):
+    """Schmidl-Cox searchForSync on 320 capture buffers (two pilot layouts, random offsets / SNR / CFO, tone bursts and
+    truncated preambles in front, noise-only buffers) decided by the GPU and by the UNMODIFIED reference (oracle/_ref)
+    on the host cores: found / position / CFO / noise floor must agree bit for bit."""
+    import threading
+    import gen_golden
+    if not po.Ref.available():
+        pytest.skip("oracle/_ref/libria_ref.so not present on this box")
+    g = golden("cox_sync")
+    ref = po.Ref()
+    ref.cox_search(np.zeros(12000, np.float32))          # static-table warm-up before threading
+    rng = np.random.default_rng(4711)
+    for mod, rate, pm, pr, tx in (("QAM16", "R1_2", po.QAM16, po.R1_2, g["tx"]), ("DQPSK", "R1_4", po.DQPSK, po.R1_4, g["preamble_dqpsk_r14"])):
+        e = engine(mod, rate)
+        n, L = 160, 28000
+        X = np.zeros((n, L), np.float32)
+        nf = np.zeros(n, np.float32)
+        for t in range(n):
+            off = int(rng.integers(0, 16000)) if t % 9 else -1
+            variant = (0, 0, 1, 0, 2)[t % 5] if mod == "QAM16" else 0
+            case = (L, off, float(rng.uniform(8, 36)), float(rng.uniform(-45, 45)), 0.8, 0.0, variant)
+            X[t], _ = gen_golden.cox_buffer(tx, case, 5000 + t)
+            nf[t] = (0.0, 0.0, 3e-4)[t % 3]
+        out = _cox_fields(e.sync_cox(dev(X), 0.8, dev(nf)))
+        exp = np.zeros((n, 4), np.float32)
+
+        def work(lo, hi):
+            for i in range(lo, hi):
+                o3, nfa = ref.cox_search(X[i], 0.8, float(nf[i]), pm, pr)
+                exp[i, :3] = o3; exp[i, 3] = nfa
+        nt = 16
+        th = [threading.Thread(target=work, args=(k * n // nt, (k + 1) * n // nt)) for k in range(nt)]
+        [t.start() for t in th]; [t.join() for t in th]
+        bad = [i for i in range(n) if not np.array_equal(out[i].view(np.uint32), exp[i].view(np.uint32))]
+        assert not bad, (mod, len(bad), bad[:5], out[bad[0]], exp[bad[0]])
+        assert n // 3 <= int(exp[:, 0].sum()) < n
+
+
 def test_cox_sync_edge_cases(oracle):
     """Empty batch, buffers below MIN_SEARCH_SAMPLES / below preamble + window (demodulator.cpp:1454,1466: not
     found, noise floor untouched), silence, a constant, oversize rejected."""
