@@ -202,6 +202,53 @@ __device__ __forceinline__ float min_abs(float x, float b) {
     asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(d) : "v"(x), "v"(b));
     return d;
 }
+__device__ __forceinline__ float min3_abs(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float med3_abs3(float a, float b, float c) {
+    float d;
+    asm("v_med3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float min2_abs(float a, float b) {
+    float d;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float max2_abs(float a, float b) {
+    float d;
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {   // finite operands: no quieting wanted
+    float d;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// The two smallest magnitudes of w[0..N-1] (with multiplicity: a repeated minimum gives mid == lo) as a small
+// tournament of 3-input selections instead of the 2-ops-per-element running update: triples give (min3, med3),
+// two (lo, mid) pairs merge as lo = min(l1, l2), mid = med3(l1, l2, min(m1, m2)), a single element joins as
+// mid = med3(|e|, lo, mid), lo = min(|e|, lo).  Selections only: the results are the same values bit for bit.
+template <int N>
+__device__ __forceinline__ void two_smallest_abs(const float (&w)[N], float& lo, float& mid) {
+    static_assert(N >= 2 && N <= 7, "row degree");
+    if constexpr (N == 2) { lo = min2_abs(w[0], w[1]); mid = max2_abs(w[0], w[1]); }
+    else {
+        lo = min3_abs(w[0], w[1], w[2]); mid = med3_abs3(w[0], w[1], w[2]);
+        if constexpr (N >= 6) {
+            const float l2 = min3_abs(w[3], w[4], w[5]), m2 = med3_abs3(w[3], w[4], w[5]);
+            const float x = min_raw(mid, m2);
+            mid = __builtin_amdgcn_fmed3f(lo, l2, x);
+            lo = min_raw(lo, l2);
+            if constexpr (N == 7) { mid = med3_abs(w[6], lo, mid); lo = min_abs(w[6], lo); }
+        } else {
+            if constexpr (N >= 4) { mid = med3_abs(w[3], lo, mid); lo = min_abs(w[3], lo); }
+            if constexpr (N >= 5) { mid = med3_abs(w[4], lo, mid); lo = min_abs(w[4], lo); }
+        }
+    }
+}
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {   // (mask & a) | (~mask & b)
     uint32_t d;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
@@ -272,14 +319,12 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             const float pvr = st.pv[r];                   // identity edge: the last edge of the row
             uint32_t par = f2u(st.pt[r]);
             uint32_t sgn = f2u(pvr);
-            float min1 = __builtin_fabsf(pvr), min2 = 3.402823466e+38f;   // FLT_MAX, the reference's initial min_abs
-            float v[NE];
+            float min1, min2;
+            float v[NE + 1];                               // v[NE] = the identity edge
 #pragma unroll
-            for (int s = 0; s < NE; ++s) {
-                v[s] = __builtin_amdgcn_fmed3f(t[s] - cold[s], lo, hi);
-                min2 = med3_abs(v[s], min1, min2);
-                min1 = min_abs(v[s], min1);
-            }
+            for (int s = 0; s < NE; ++s) v[s] = __builtin_amdgcn_fmed3f(t[s] - cold[s], lo, hi);
+            v[NE] = pvr;
+            two_smallest_abs<NE + 1>(v, min1, min2);
 #pragma unroll
             for (int s = 0; s < NE; s += 2) {             // parity of the hard bits / product of the signs: xor3
                 if (s + 1 < NE) {
@@ -291,23 +336,22 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
                 }
             }
             syn |= par;
-            // (sign * min_abs) * factor == sign * (min_abs * factor): scale the two candidates once per row and
-            // give them the row's sign product; an edge then removes its own sign: c2v = cand ^ (v & signbit),
-            // one v_bitop3 (0x78: S0 ^ (S1 & S2))
-            const uint32_t m1s = bfi(kAbs, f2u(min1 * factor), sgn), m2s = bfi(kAbs, f2u(min2 * factor), sgn);
+            // min over the OTHER edges of edge e is min2 if |v_e| == min1 (ties: min2 == min1), else min1, with the sign
+            // product of the others.  Selection without a compare: x = sign(v_e) * min(|v_e|, min2) is one v_med3
+            // (v, min2, -min2) and carries the bits of min1 in the first case, of min2 in the second; xor with
+            // bits(min1) ^ bits(min2) ^ row-sign swaps the magnitude to the other candidate and turns the edge's own
+            // sign into the product of the others.  (sign * min_abs) * factor is then the reference's own order.
+            const uint32_t dS = bfi(kAbs, f2u(min1) ^ f2u(min2), sgn);
             static_for<0, NE>([&](auto S_) __attribute__((always_inline)) {
                 constexpr int s = decltype(S_)::value;
-                // min over the OTHER edges: min2 if this edge holds the minimum (ties: min2 == min1)
-                const uint32_t mn = (__builtin_fabsf(v[s]) == min1) ? m2s : m1s;
-                uint32_t out = __builtin_amdgcn_bitop3_b32(mn, f2u(v[s]), kSign, 0x78);
+                uint32_t out = f2u(u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(v[s], min2, -min2))) * factor);
                 // padded lanes of a mixed slot keep -FLT_MAX as this edge's c2v
                 if constexpr (s >= S::nm(r)) out = bfi(st.keep[I::mix_off(r) + s - S::nm(r)], out, kNegMax);
                 lds_store_tid<256 * (off + s)>(m0base, u2f(out));
                 if constexpr (kCvRegs) st.cv[off + s] = u2f(out);
             });
             {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
-                const uint32_t mn = (__builtin_fabsf(pvr) == min1) ? m2s : m1s;
-                const float c2v = u2f(__builtin_amdgcn_bitop3_b32(mn, f2u(pvr), kSign, 0x78));
+                const float c2v = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(pvr, min2, -min2))) * factor;
                 const float tot = st.lp[r] + c2v;
                 st.pv[r] = __builtin_amdgcn_fmed3f(tot - c2v, -50.0f, 50.0f);
                 st.pt[r] = tot;
