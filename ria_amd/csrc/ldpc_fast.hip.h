@@ -298,7 +298,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
 #pragma unroll
     for (int r = 0; r < S::NR; ++r) { st.pv[r] = st.lp[r]; st.pt[r] = 0.0f; }
     wave_sync();
-    float lo = -__builtin_inff(), hi = __builtin_inff();
+    float hi = __builtin_inff();
     int it = 0;
     bool success = false;
     for (; it < max_iter; ++it) {
@@ -322,9 +322,16 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             float min1, min2;
             float v[NE + 1];                               // v[NE] = the identity edge
 #pragma unroll
-            for (int s = 0; s < NE; ++s) v[s] = __builtin_amdgcn_fmed3f(t[s] - cold[s], lo, hi);
+            // v2c = clamp(tot - c2v, -50, 50) (no clamp in the first iteration: hi = inf).  The clamp only ever acts
+            // on magnitudes, and the row needs just the two smallest of them and the signs: min_k min(|x_k|, hi) =
+            // min(min_k |x_k|, hi), so the tournament runs on the unclamped differences and its two results are
+            // clamped (2 operations per row instead of one per edge); min(|x|, min2) below is unchanged by the
+            // clamp of x because min2 <= hi.
+            for (int s = 0; s < NE; ++s) v[s] = t[s] - cold[s];
             v[NE] = pvr;
             two_smallest_abs<NE + 1>(v, min1, min2);
+            min1 = min_raw(min1, hi);
+            min2 = min_raw(min2, hi);
 #pragma unroll
             for (int s = 0; s < NE; s += 2) {             // parity of the hard bits / product of the signs: xor3
                 if (s + 1 < NE) {
@@ -353,12 +360,12 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
                 const float c2v = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(pvr, min2, -min2))) * factor;
                 const float tot = st.lp[r] + c2v;
-                st.pv[r] = __builtin_amdgcn_fmed3f(tot - c2v, -50.0f, 50.0f);
+                st.pv[r] = tot - c2v;                    // clamped where it is used (see above)
                 st.pt[r] = tot;
             }
         });
         if (it > 0 && __ballot(static_cast<int>(syn) < 0) == 0ull) { success = true; --it; break; }
-        lo = -50.0f; hi = 50.0f;
+        hi = 50.0f;
         wave_sync();
         // information columns: tot = llr + sum of c2v in ascending check order
         // (v_pk_add_f32 pairing of rounds / edges was measured: fewer VALU instructions, same time -- the
