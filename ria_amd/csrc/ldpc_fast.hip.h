@@ -40,6 +40,7 @@ namespace ria {
 struct ShapeR12 {   // R1/2: m = 324, k = 324
     static constexpr int NR = 6, NC = 6;
     static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
+    static constexpr int kCascadeCv = 8, kPhase0Cv = 24;   // own-c2v slots kept in VGPRs between iterations (LDS reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 4, 2, 1}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 5, 4, 2, 1, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {5, 4, 4, 4, 4, 4}; return t[r]; }
@@ -47,6 +48,7 @@ struct ShapeR12 {   // R1/2: m = 324, k = 324
 struct ShapeR13 {   // R1/3 entry of the rate table: same (324,324) parameters, H seeded differently
     static constexpr int NR = 6, NC = 6;
     static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
+    static constexpr int kCascadeCv = 8, kPhase0Cv = 24;   // own-c2v slots kept in VGPRs between iterations (LDS reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 3, 3, 1}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 5, 3, 3, 1, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {6, 4, 4, 4, 4, 4}; return t[r]; }
@@ -54,6 +56,7 @@ struct ShapeR13 {   // R1/3 entry of the rate table: same (324,324) parameters, 
 struct ShapeR14 {   // m = 486, k = 162
     static constexpr int NR = 8, NC = 3;
     static constexpr int kCascadeWaves = 2;   // waves/SIMD the cascade kernel is held to (its register budget)
+    static constexpr int kCascadeCv = 0, kPhase0Cv = 0;   // own-c2v slots kept in VGPRs between iterations (LDS reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 5, 5, 4, 3, 2, 2}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 5, 4, 3, 2, 2, 1}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {13, 12, 12}; return t[r]; }
@@ -61,6 +64,7 @@ struct ShapeR14 {   // m = 486, k = 162
 struct ShapeR23 {   // m = 216, k = 432
     static constexpr int NR = 4, NC = 7;
     static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
+    static constexpr int kCascadeCv = 0, kPhase0Cv = 0;   // own-c2v slots kept in VGPRs between iterations (LDS reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6, 4}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 3}; return t[r]; }
@@ -68,6 +72,7 @@ struct ShapeR23 {   // m = 216, k = 432
 struct ShapeR34 {   // m = 162, k = 486 (161 information columns have no edge at all)
     static constexpr int NR = 3, NC = 8;
     static constexpr int kCascadeWaves = 4;   // waves/SIMD the cascade kernel is held to (its register budget)
+    static constexpr int kCascadeCv = 0, kPhase0Cv = 0;   // own-c2v slots kept in VGPRs between iterations (LDS reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 0, 0}; return t[r]; }
@@ -75,6 +80,7 @@ struct ShapeR34 {   // m = 162, k = 486 (161 information columns have no edge at
 struct ShapeR56 {   // m = 108, k = 540
     static constexpr int NR = 2, NC = 9;
     static constexpr int kCascadeWaves = 5;   // waves/SIMD the cascade kernel is held to (its register budget)
+    static constexpr int kCascadeCv = 0, kPhase0Cv = 0;   // own-c2v slots kept in VGPRs between iterations (LDS reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 0, 0, 0, 0, 0}; return t[r]; }
@@ -135,7 +141,7 @@ struct FastState {
     uint32_t rv[I::TS];            // gather addresses of the check pass
     uint32_t cs[I::TD > 0 ? I::TD : 1];   // gather addresses of the column pass
     uint32_t keep[I::TM > 0 ? I::TM : 1]; // mixed slots: all ones on lanes that own an edge there, 0 on padded lanes
-    float cv[kCvRegs ? I::TS : 1]; // (kCvRegs) c2v of the row's own edges as written in the previous iteration
+    float cv[I::TS];               // c2v of the row's own edges as written in the previous iteration (slots < NCV of fast_decode only)
     float li[S::NC];               // information-column LLRs (sorted position q = lane + 64 r)
     float lp[S::NR];               // identity-column LLRs (row position p = lane + 64 r)
     float pv[S::NR];               // v2c of the identity edges
@@ -274,7 +280,7 @@ __device__ __forceinline__ float llr_canon(float x) {
 //   column pass  tot[j] = llr[j] + sum of its c2v slots in ascending check order -> ONE store per column.
 // Zeros stay canonical: x - y and x + y only give -0.0 from (-0.0, +-0.0) operands, the LLRs are
 // canonical and a c2v of -0.0 can only be added to or subtracted from a canonical value.
-template <class S>
+template <class S, int NCV = (kCvRegs ? 1024 : 0)>
 __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned char* __restrict__ lds,
                                   float factor, int max_iter, int lane, bool* ok) {
     using I = ShapeInfo<S>;
@@ -288,7 +294,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
 #pragma unroll
         for (int s = 0; s < S::ne(r); ++s) {
             const float v0 = (s >= S::nm(r)) ? u2f(bfi(st.keep[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)], 0u, kNegMax)) : 0.0f;
-            if constexpr (kCvRegs) st.cv[I::row_off(r) + s] = v0;
+            if (I::row_off(r) + s < NCV) st.cv[I::row_off(r) + s] = v0;
             else lds_sf(lane4 + 256u * (I::row_off(r) + s), v0);
         }
     });
@@ -311,7 +317,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
                 t[s] = lds_f(st.rv[off + s]);
-                if constexpr (kCvRegs) cold[s] = st.cv[off + s];
+                if (off + s < NCV) cold[s] = st.cv[off + s];
                 else cold[s] = lds_f(lane4 + 256u * (off + s));
             }
             // |x| rides on the float source modifiers (free), min1/min2 are v_med3_f32: med3(a, b, -inf) =
@@ -355,7 +361,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
                 // padded lanes of a mixed slot keep -FLT_MAX as this edge's c2v
                 if constexpr (s >= S::nm(r)) out = bfi(st.keep[I::mix_off(r) + s - S::nm(r)], out, kNegMax);
                 lds_store_tid<256 * (off + s)>(m0base, u2f(out));
-                if constexpr (kCvRegs) st.cv[off + s] = u2f(out);
+                if constexpr (off + s < NCV) st.cv[off + s] = u2f(out);
             });
             {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
                 const float c2v = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(pvr, min2, -min2))) * factor;
@@ -504,14 +510,14 @@ __device__ inline void fast_load_staged(FastState<S>& st, const float* __restric
 
 // decode codeword `fc` (= frame*4 + cw) with factor index f and record the result; staged != nullptr: the
 // codeword's de-interleaved input (fast_stage_kernel) instead of the gather from the frame
-template <class S>
+template <class S, int NCV = 0>
 __device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, unsigned char* lds, unsigned fc, int f, int lane,
                                  const float* staged = nullptr) {
     const FastCode& c = A.c;
     if (staged) fast_load_staged(st, staged, lane);
     else fast_gather_llr(st, c, A.llr + static_cast<size_t>(fc >> 2) * A.llr_stride, A.gather, fc & 3, lane);
     bool ok;
-    int it = fast_decode(st, c, lds, kFactors[f], c.max_iter, lane, &ok);
+    int it = fast_decode<S, NCV>(st, c, lds, kFactors[f], c.max_iter, lane, &ok);
     if (ok) fast_pack(st, c, lds, A.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw,
                       c.bytes_per_cw, lane);
     if (lane == 0) { A.res[fc].state[f] = ok ? 2 : 1; A.res[fc].iters[f] = static_cast<uint16_t>(it); }
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
     for (unsigned u = blockIdx.x; u < total; u += gridDim.x)
-        fast_unit(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane, A.staged + static_cast<size_t>(u >> 2) * kStageFloats);
+        fast_unit<S, S::kPhase0Cv>(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane, A.staged + static_cast<size_t>(u >> 2) * kStageFloats);
 }
 
 // ------------------------------------------------------------------------------------------------ chain
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
         const uint32_t h = A.l1hash[li];
         float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
-        const int it = fast_decode(st, c, smem, factor, c.max_iter, lane, &ok);
+        const int it = fast_decode<S, S::kCascadeCv>(st, c, smem, factor, c.max_iter, lane, &ok);
         if (ok) {
             unsigned int prev = 0;
             if (lane == 0) prev = atomicMin(&A.best[e], a);
