@@ -477,7 +477,7 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     {   // the lane/slot assignment is annealed for LDS bank conflicts (host_tables.hpp): once per rate and process
         static std::mutex mu;
         static std::map<std::pair<int, int>, CoreTables> cache;
-        const int moves = getenv("RIA_BANKOPT_MOVES") ? atoi(getenv("RIA_BANKOPT_MOVES")) : 60000;
+        const int moves = getenv("RIA_BANKOPT_MOVES") ? atoi(getenv("RIA_BANKOPT_MOVES")) : 1000000;   // ~3.5 s, once per rate and process; cost 175 (60k moves) -> 152 passes, floor 98
         std::lock_guard<std::mutex> lock(mu);
         auto key = std::make_pair(static_cast<int>(cfg->code_rate), moves);
         auto it = cache.find(key);
