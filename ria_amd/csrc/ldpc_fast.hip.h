@@ -617,8 +617,14 @@ __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
-    for (unsigned u = blockIdx.x; u < total; u += gridDim.x)
+    for (;;) {   // persistent waves over an atomic queue (ctl->next_z).  Every lane takes part in the atomic (lane 0
+                 // adds 1, the others 0): a lane-0-only atomic inside this loop is compiled into a loop nest that
+                 // never leaves unit 0 (hipcc 7.2, control-flow structurizer); this form has no divergent branch
+        unsigned u = atomicAdd(&A.ctl->next_z, lane == 0 ? 1u : 0u);
+        u = __builtin_amdgcn_readfirstlane(u);   // scalar: the loop control and every address derived from u stay uniform
+        if (u >= total) break;
         fast_unit<S, S::kPhase0Cv>(st, A, smem, A.list1[u >> 2], 1 + static_cast<int>(u & 3u), lane, A.staged + static_cast<size_t>(u >> 2) * kStageFloats);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ chain
@@ -708,11 +714,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
     for (;;) {
         unsigned int u = 0;
         if (lane == 0) u = atomicAdd(&A.ctl->next_unit, 1u);
-        u = __shfl(u, 0);
+        u = __builtin_amdgcn_readfirstlane(u);   // scalar: the loop control and every address derived from u stay uniform
         if (u >= total) break;
         const unsigned int a = u / n_entries, e = u - a * n_entries;
         unsigned int b = __hip_atomic_load(&A.best[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b = __shfl(b, 0);
+        b = __builtin_amdgcn_readfirstlane(b);
         if (b < a) continue;  // an earlier attempt already succeeded: this one can never be chosen
         const unsigned int fc = A.entries[e];
         const unsigned int li = A.l1idx[fc];
@@ -729,13 +735,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
         if (ok) {
             unsigned int prev = 0;
             if (lane == 0) prev = atomicMin(&A.best[e], a);
-            prev = __shfl(prev, 0);
+            prev = __builtin_amdgcn_readfirstlane(prev);
             if (a < prev) {   // best so far: publish under the entry's lock (held for one 40..68-byte store)
                 CascadeWin* w = A.win + e;
                 if (lane == 0) while (atomicCAS(&w->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
                 __threadfence();
                 unsigned int cur = __hip_atomic_load(&A.best[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cur = __shfl(cur, 0);
+                cur = __builtin_amdgcn_readfirstlane(cur);
                 if (cur == a) {
                     fast_pack(st, c, smem, w->bytes, c.bytes_per_cw, lane);
                     if (lane == 0) w->iters = static_cast<unsigned int>(it);

@@ -579,7 +579,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
             stage("stage");
         }
         if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB))
-            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, 16384)), dim3(64), wb, s, A);
+            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, 3072)), dim3(64), wb, s, A);
         stage("phase0");
         hipLaunchKernelGGL(fast_chain_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
         stage("chain");
