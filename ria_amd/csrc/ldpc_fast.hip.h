@@ -712,8 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
     FastState<S> st;
     fast_load_tables(st, c, smem, lane);
     for (;;) {
-        unsigned int u = 0;
-        if (lane == 0) u = atomicAdd(&A.ctl->next_unit, 1u);
+        unsigned int u = atomicAdd(&A.ctl->next_unit, lane == 0 ? 1u : 0u);   // all lanes take part: see fast_phase0_kernel
         u = __builtin_amdgcn_readfirstlane(u);   // scalar: the loop control and every address derived from u stay uniform
         if (u >= total) break;
         const unsigned int a = u / n_entries, e = u - a * n_entries;
