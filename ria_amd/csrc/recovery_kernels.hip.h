@@ -246,6 +246,7 @@ struct RecoveryArgs {
     unsigned int* list2;         // [16*n_frames] (fc << 3) | factor index
     unsigned int* n_stage2;      // counter
     unsigned int* stage2;        // [n_frames] frames whose stage 1 failed
+    unsigned int* next_fill;     // counter: work queue head of recovery_fill_kernel
     int list_units_now;          // recovery_list_kernel also lists the missing re-decodes (host-search path)
     // host-search staging (RIA_RECOVERY_HOST=1 only)
     uint8_t* info_c;             // [n_flagged][4*bpc]
@@ -274,7 +275,10 @@ __global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
     if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, R.d.c, smem, threadIdx.x);
-    for (unsigned u = blockIdx.x; u < total; u += gridDim.x) {     // static unit -> workgroup map
+    for (;;) {   // persistent waves over an atomic queue (all-lane atomic form: see fast_phase0_kernel)
+        unsigned u = atomicAdd(R.next_fill, threadIdx.x == 0 ? 1u : 0u);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= total) break;
         const unsigned e = R.list2[u];
         fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
     }

@@ -256,7 +256,7 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
     RecoveryArgs R{};
     R.d = D;
     unsigned int* rctl = h->d_rctl + 4 * slot;
-    R.n_flagged = rctl; R.n_list2 = rctl + 1; R.n_stage2 = rctl + 2;
+    R.n_flagged = rctl; R.n_list2 = rctl + 1; R.n_stage2 = rctl + 2; R.next_fill = rctl + 3;
     R.flagged = h->d_flagged + ws_off; R.list2 = h->d_list2 + static_cast<size_t>(ws_off) * 16; R.stage2 = h->d_stage2 + ws_off;
     R.list_units_now = 0;
     if (hipMemsetAsync(rctl, 0, 16, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
@@ -265,7 +265,7 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
     hipLaunchKernelGGL(recovery_stage1_kernel, dim3(n_frames), dim3(64), rl, s, R);
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(std::min(n_frames * 16, 16384)), dim3(64), h->wave_lds, s, R);
+        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(std::min(n_frames * 16, 3072)), dim3(64), h->wave_lds, s, R);
     });
     hipLaunchKernelGGL(recovery_stage2_kernel, dim3(n_frames), dim3(64), rl, s, R);
     if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery kernel launch failed");
@@ -282,7 +282,7 @@ static int run_crc_recovery_host(ria_gpu_handle h, const FastDecodeArgs& D, hipS
     const int bpc = h->geo.bytes_per_codeword, ib = h->geo.info_bytes_per_frame;
     RecoveryArgs R{};
     R.d = D;
-    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1;
+    R.n_flagged = h->d_rctl; R.n_list2 = h->d_rctl + 1; R.next_fill = h->d_rctl + 3;
     R.flagged = h->d_flagged; R.list2 = h->d_list2; R.list_units_now = 1;
     R.info_c = h->d_info_c; R.rows_c = h->d_rows_c; R.redec_ok = h->d_redec_ok; R.redec_bytes = h->d_redec_bytes;
 #define R_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -291,7 +291,7 @@ static int run_crc_recovery_host(ria_gpu_handle h, const FastDecodeArgs& D, hipS
     const int wb = h->wave_lds;
     dispatch_shape(h->cfg.code_rate, [&](auto sh) {
         using S = decltype(sh);
-        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(n_frames * 16), dim3(64), wb, s, R);
+        hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(std::min(n_frames * 16, 3072)), dim3(64), wb, s, R);
     });
     hipLaunchKernelGGL(recovery_gather_kernel, dim3(n_frames), dim3(256), 0, s, R);
     hipLaunchKernelGGL(recovery_status_gather_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, h->d_rctl, h->d_flagged,
