@@ -4,6 +4,7 @@ Bit-exact for bytes, iteration counts and float32 bit patterns unless a toleranc
 import ctypes
 import ctypes.util
 
+import os
 import numpy as np
 import pytest
 
@@ -759,7 +760,7 @@ def test_other_modes_vs_the_reference_library(mod, rate, kind, snr):
     from ria_amd import capi
     e = engine(mod, rate)
     pm, pr = capi.MOD[mod], capi.RATE[rate]
-    n, seed, first = 384, 8800 + 16 * pm + pr, 1000
+    n, seed, first = int(os.environ.get("RIA_MODES_SAMPLE", "384")), 8800 + 16 * pm + pr, 1000
     bpc, bps = int(e.geo.bytes_per_codeword), int(e.geo.bits_per_symbol)
     info = e.make_frames(seed, first, n)
     x = e.tx(info, peak=0.8)
