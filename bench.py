@@ -131,8 +131,11 @@ def main():
     B = args.batch
     e = RxEngine("QAM16", "R1_2", device=local, max_batch=B)
     n_sets = args.steps + args.warmup
+    # every step gets its own input batch up to 16 resident batches (29 GB at the default size); longer runs cycle
+    # through them - the work per step is the same, nothing is cached between steps
+    n_pool = min(n_sets, 16)
     batches, infos = [], []
-    for s in range(n_sets):
+    for s in range(n_pool):
         first = (s * world + rank) * B                   # global frame index: results independent of N
         info = e.make_frames(seed, first, B)
         x = e.tx(info, peak=0.8)
@@ -150,18 +153,18 @@ def main():
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        e.rx(batches[s], out=out)
+        e.rx(batches[s % n_pool], out=out)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, n_sets):
-        e.rx(batches[s], out=out)
+        e.rx(batches[s % n_pool], out=out)
     barrier()
     elapsed = time.perf_counter() - t0
 
     # correctness counters of the last step (outside the timed region)
     st = e.decode_status(out[1])
     frames_ok = int((st["cw_ok"].all(axis=1) & st["frame_valid"].astype(bool)).sum())
-    bytes_ok = int((out[0] == infos[-1]).all(dim=1).sum().item())
+    bytes_ok = int((out[0] == infos[(n_sets - 1) % n_pool]).all(dim=1).sum().item())
     cnt = torch.tensor([B * args.steps, frames_ok, bytes_ok, int(st["iterations"].sum())], dtype=torch.int64, device=cdev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
