@@ -16,7 +16,7 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-
 def _sources():
     out = [os.path.join(HERE, "..", "include", "ria_gpu.h")]
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".h", ".hpp")):
+        if f.endswith((".hip", ".h", ".hpp", ".inc")):
             out.append(os.path.join(CSRC, f))
     return out
 

@@ -600,6 +600,118 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
     return t;
 }
 
+// ---- shipped layouts -------------------------------------------------------------------------------
+// The annealer is deterministic but slow to converge (152 conflict passes per iteration after 1 M moves, 140 after
+// 16 M), so the layouts of the six rates are annealed offline by tools/gen_core_layouts.cpp and shipped as data
+// (core_layouts.inc).  A shipped layout is used only after validate_core_tables() has checked it against the H the
+// library generates: every address table entry must be the one the decoder's indexing scheme implies.
+struct SavedCoreTables { int rate; int n; const uint16_t* data; };
+// flat form: ts td n_mixed NR NC tot_word zero_word dump_word cost_before cost_after floor | ne[NR] nm[NR] dv[NC]
+//            | check_at[64 NR] col_at[64 NC] col_pos[k] row_addr[64 ts] col_addr[64 td]
+inline std::vector<uint16_t> flatten_core_tables(const CoreTables& t) {
+    std::vector<uint16_t> o;
+    const int NR = static_cast<int>(t.ne.size()), NC = static_cast<int>(t.dv.size());
+    for (int v : {t.ts, t.td, t.n_mixed, NR, NC, t.tot_word, t.zero_word, t.dump_word, t.conflict_cost_before, t.conflict_cost_after, t.conflict_floor})
+        o.push_back(static_cast<uint16_t>(v));
+    for (int v : t.ne) o.push_back(static_cast<uint16_t>(v));
+    for (int v : t.nm) o.push_back(static_cast<uint16_t>(v));
+    for (int v : t.dv) o.push_back(static_cast<uint16_t>(v));
+    for (const auto* a : {&t.check_at, &t.col_at, &t.col_pos, &t.row_addr, &t.col_addr}) o.insert(o.end(), a->begin(), a->end());
+    return o;
+}
+inline bool unflatten_core_tables(const LdpcCode& c, const uint16_t* d, int n, CoreTables& t) {
+    if (n < 11) return false;
+    int p = 0;
+    t = CoreTables{};
+    t.k = c.k; t.m = c.m;
+    t.ts = d[p++]; t.td = d[p++]; t.n_mixed = d[p++];
+    const int NR = d[p++], NC = d[p++];
+    t.tot_word = d[p++]; t.zero_word = d[p++]; t.dump_word = d[p++];
+    t.conflict_cost_before = d[p++]; t.conflict_cost_after = d[p++]; t.conflict_floor = d[p++];
+    const long need = 11L + 2L * NR + NC + 64L * NR + 64L * NC + c.k + 64L * std::max(1, t.ts) + 64L * std::max(1, t.td);
+    if (NR != (c.m + 63) / 64 || NC != (c.k + 63) / 64 || need != n) return false;
+    auto take = [&](std::vector<int>& v, int cnt) { v.assign(d + p, d + p + cnt); p += cnt; };
+    auto take16 = [&](std::vector<uint16_t>& v, int cnt) { v.assign(d + p, d + p + cnt); p += cnt; };
+    take(t.ne, NR); take(t.nm, NR); take(t.dv, NC);
+    take16(t.check_at, 64 * NR); take16(t.col_at, 64 * NC); take16(t.col_pos, c.k);
+    take16(t.row_addr, 64 * std::max(1, t.ts)); take16(t.col_addr, 64 * std::max(1, t.td));
+    return true;
+}
+// true iff the tables describe a valid layout of code c: permutations, round structure, and every gather address
+inline bool validate_core_tables(const LdpcCode& c, const CoreTables& t) {
+    const int k = c.k, m = c.m, NR = (m + 63) / 64, NC = (k + 63) / 64;
+    if (t.k != k || t.m != m || static_cast<int>(t.ne.size()) != NR || static_cast<int>(t.nm.size()) != NR || static_cast<int>(t.dv.size()) != NC) return false;
+    std::vector<int> row_off(NR + 1, 0), col_off(NC + 1, 0);
+    int mixed = 0;
+    for (int r = 0; r < NR; ++r) { if (t.nm[r] > t.ne[r] || t.ne[r] < 0) return false; row_off[r + 1] = row_off[r] + t.ne[r]; mixed += t.ne[r] - t.nm[r]; }
+    for (int r = 0; r < NC; ++r) col_off[r + 1] = col_off[r] + t.dv[r];
+    if (t.ts != row_off[NR] || t.td != col_off[NC] || t.n_mixed != mixed) return false;
+    if (t.tot_word != 64 * t.ts || t.zero_word != t.tot_word + 64 * NC || t.dump_word != t.zero_word + 64) return false;
+    if (static_cast<int>(t.check_at.size()) != 64 * NR || static_cast<int>(t.col_at.size()) != 64 * NC || static_cast<int>(t.col_pos.size()) != k) return false;
+    if (static_cast<int>(t.row_addr.size()) != 64 * std::max(1, t.ts) || static_cast<int>(t.col_addr.size()) != 64 * std::max(1, t.td)) return false;
+    std::vector<int> row_pos(m, -1), seen_col(k, 0);
+    for (int p = 0; p < 64 * NR; ++p) if (t.check_at[p] != 0xFFFF) { const int i = t.check_at[p]; if (i >= m || row_pos[i] >= 0) return false; row_pos[i] = p; }
+    for (int i = 0; i < m; ++i) if (row_pos[i] < 0) return false;
+    for (int q = 0; q < 64 * NC; ++q) if (t.col_at[q] != 0xFFFF) { const int j = t.col_at[q]; if (j >= k || seen_col[j] || t.col_pos[j] != q) return false; seen_col[j] = 1; }
+    for (int j = 0; j < k; ++j) if (!seen_col[j]) return false;
+    // information edges of every check (the last entry of c.rows[i] is its identity column k+i) and, per column, its checks ascending
+    std::vector<std::vector<int>> col_checks(k);
+    for (int i = 0; i < m; ++i) for (size_t e = 0; e + 1 < c.rows[i].size(); ++e) col_checks[c.rows[i][e]].push_back(i);
+    std::vector<std::vector<int>> slot_col(m);       // column read by slot s of check i, from row_addr
+    for (int i = 0; i < m; ++i) {
+        const int p = row_pos[i], r = p / 64, l = p % 64, deg = static_cast<int>(c.rows[i].size()) - 1;
+        if (deg > t.ne[r] || deg < t.nm[r]) return false;
+        std::vector<int> want(c.rows[i].begin(), c.rows[i].end() - 1), got;
+        for (int s = 0; s < t.ne[r]; ++s) {
+            const int a = t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l];
+            if (a % 4) return false;
+            const int w = a / 4;
+            if (s < deg) {
+                const int q = w - t.tot_word;
+                if (q < 0 || q >= 64 * NC || t.col_at[q] == 0xFFFF) return false;
+                got.push_back(t.col_at[q]);
+            } else if (w != t.zero_word + l) return false;
+        }
+        slot_col[i] = got;
+        std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
+        if (want != got) return false;
+    }
+    for (int r = 0; r < NR; ++r) for (int l = 0; l < 64; ++l) if (t.check_at[64 * r + l] == 0xFFFF)
+        for (int s = 0; s < t.ne[r]; ++s) if (t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l] != 4 * (t.zero_word + l)) return false;
+    for (int cr = 0; cr < NC; ++cr) for (int l = 0; l < 64; ++l) {
+        const int cc = t.col_at[64 * cr + l] == 0xFFFF ? -1 : t.col_at[64 * cr + l];
+        const int deg = cc < 0 ? 0 : static_cast<int>(col_checks[cc].size());
+        if (deg > t.dv[cr]) return false;
+        for (int d = 0; d < t.dv[cr]; ++d) {
+            const int a = t.col_addr[static_cast<size_t>(64) * (col_off[cr] + d) + l];
+            int w = t.zero_word + l;
+            if (d < deg) {
+                const int i = col_checks[cc][d];
+                int s = -1;
+                for (size_t q = 0; q < slot_col[i].size(); ++q) if (slot_col[i][q] == cc) s = static_cast<int>(q);
+                if (s < 0) return false;
+                w = 64 * (row_off[row_pos[i] / 64] + s) + row_pos[i] % 64;
+            }
+            if (a != 4 * w) return false;
+        }
+    }
+    return true;
+}
+
+#if __has_include("core_layouts.inc")
+#include "core_layouts.inc"
+#define RIA_HAVE_SAVED_LAYOUTS 1
+#endif
+// the shipped layout of a rate, if there is one and it is a valid layout of the H this build generates
+inline bool load_saved_core_tables(const LdpcCode& c, CoreTables& t) {
+#ifdef RIA_HAVE_SAVED_LAYOUTS
+    for (const SavedCoreTables& sv : kSavedLayouts)
+        if (sv.rate == c.rate) return unflatten_core_tables(c, sv.data, sv.n, t) && validate_core_tables(c, t);
+#endif
+    (void)c; (void)t;
+    return false;
+}
+
 // ---------------------------------------------------------------- Zadoff-Chu preamble (sync::ZCSync)
 // zc_sync.hpp:420-436 (generateZC, N = 127 odd), :147-157 (8x linear interpolation), :133-190 (preamble).
 // The float functions are devmath.h's host build (bit-identical to glibc, tests/test_devmath_host.py).

@@ -474,14 +474,21 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_llr_ws),
                          static_cast<size_t>(h->cfg.max_batch) * g.llrs_per_frame * sizeof(float)));
 
-    {   // the lane/slot assignment is annealed for LDS bank conflicts (host_tables.hpp): once per rate and process
+    {   // the lane/slot assignment against LDS bank conflicts (host_tables.hpp): the layout annealed offline and shipped
+        // with the library (validated against this build's H), or - RIA_BANKOPT_MOVES set, or no valid shipped layout -
+        // annealed here, once per rate and process
         static std::mutex mu;
         static std::map<std::pair<int, int>, CoreTables> cache;
-        const int moves = getenv("RIA_BANKOPT_MOVES") ? atoi(getenv("RIA_BANKOPT_MOVES")) : 1000000;   // ~3.5 s, once per rate and process; cost 175 (60k moves) -> 152 passes, floor 98
+        const char* mv = getenv("RIA_BANKOPT_MOVES");
+        const int moves = mv ? atoi(mv) : -1;              // -1: shipped layout, annealing (1 M moves) as the fallback
         std::lock_guard<std::mutex> lock(mu);
         auto key = std::make_pair(static_cast<int>(cfg->code_rate), moves);
         auto it = cache.find(key);
-        if (it == cache.end()) it = cache.emplace(key, build_core_tables(h->code, moves)).first;
+        if (it == cache.end()) {
+            CoreTables t;
+            if (moves >= 0 || !load_saved_core_tables(h->code, t)) t = build_core_tables(h->code, moves >= 0 ? moves : 1000000);
+            it = cache.emplace(key, std::move(t)).first;
+        }
         h->ftab = it->second;
     }
     CREATE_TRY(upload(&h->d_f_row_addr, h->ftab.row_addr));

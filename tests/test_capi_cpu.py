@@ -94,3 +94,19 @@ def test_host_built_cox_tables_match_reference_golden(golden, tmp_path):
         assert np.array_equal(a[:1152].view(np.uint32), g[f"tI_{name}"].view(np.uint32))
         assert np.array_equal(a[1152:2304].view(np.uint32), g[f"tQ_{name}"].view(np.uint32))
         assert np.array_equal(a[2305:].view(np.uint32), g[f"preamble_{name}"].view(np.uint32))
+
+
+def test_shipped_decoder_layouts_are_valid(tmp_path):
+    """ria_amd/csrc/core_layouts.inc (LDS layouts of the LDPC decoder annealed offline, tools/gen_core_layouts.cpp) must
+    pass the structural validation against the generated H for all six rates, corrupted copies must be rejected, and
+    the shipped layouts must be at least as good as what the create-time annealer reaches."""
+    import subprocess
+    exe = str(tmp_path / "layouts_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "helpers", "layouts_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l.split() for l in out.stdout.strip().split("\n")]
+    assert len(rows) == 6
+    for rate, ok, cost, floor, rej, fresh in rows:
+        assert ok == "1" and fresh == "1" and rej.split("/")[0] == rej.split("/")[1]
+        assert int(floor) <= int(cost) <= int(floor) * 1.6, (rate, cost, floor)
