@@ -311,7 +311,7 @@ struct CoreTables {
     int k = 0, m = 0;
     std::vector<int> ne, nm;           // per row round: slots unrolled, smallest row degree
     std::vector<int> dv;               // max degree per column round
-    int ts = 0, td = 0, n_mixed = 0, tot_word = 0, zero_word = 0, dump_word = 0;
+    int ts = 0, td = 0, n_mixed = 0, tot_word = 0, zero_word = 0, dump_word = 0, big_word = 0;
     std::vector<uint16_t> row_addr;    // [ts][64]
     std::vector<uint16_t> col_addr;    // [td][64]
     std::vector<uint16_t> check_at;    // [64*NR]  0xFFFF idle
@@ -566,6 +566,7 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
     t.tot_word = 64 * t.ts;
     t.zero_word = t.tot_word + 64 * L.NC;
     t.dump_word = t.zero_word + 64;
+    t.big_word = t.dump_word + 64;
     t.check_at.assign(L.check_at.size(), 0xFFFF);
     for (size_t p = 0; p < L.check_at.size(); ++p) if (L.check_at[p] >= 0) t.check_at[p] = static_cast<uint16_t>(L.check_at[p]);
     t.col_at.assign(L.col_at.size(), 0xFFFF);
@@ -577,7 +578,7 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
         for (int l = 0; l < 64; ++l) {
             const int i = L.check_at[64 * r + l];
             for (int s = 0; s < L.ne[r]; ++s) {
-                int w = t.zero_word + l;
+                int w = t.big_word + l;   // padded slot (or idle lane): the lane's big word (ldpc_fast.hip.h: kPadTotal)
                 if (i >= 0 && s < static_cast<int>(L.row_cols[i].size())) w = t.tot_word + L.col_pos[L.row_cols[i][s]];
                 t.row_addr[static_cast<size_t>(64) * (L.row_off[r] + s) + l] = static_cast<uint16_t>(4 * w);
             }
@@ -606,12 +607,12 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
 // (core_layouts.inc).  A shipped layout is used only after validate_core_tables() has checked it against the H the
 // library generates: every address table entry must be the one the decoder's indexing scheme implies.
 struct SavedCoreTables { int rate; int n; const uint16_t* data; };
-// flat form: ts td n_mixed NR NC tot_word zero_word dump_word cost_before cost_after floor | ne[NR] nm[NR] dv[NC]
+// flat form: ts td n_mixed NR NC tot_word zero_word dump_word big_word cost_before cost_after floor | ne[NR] nm[NR] dv[NC]
 //            | check_at[64 NR] col_at[64 NC] col_pos[k] row_addr[64 ts] col_addr[64 td]
 inline std::vector<uint16_t> flatten_core_tables(const CoreTables& t) {
     std::vector<uint16_t> o;
     const int NR = static_cast<int>(t.ne.size()), NC = static_cast<int>(t.dv.size());
-    for (int v : {t.ts, t.td, t.n_mixed, NR, NC, t.tot_word, t.zero_word, t.dump_word, t.conflict_cost_before, t.conflict_cost_after, t.conflict_floor})
+    for (int v : {t.ts, t.td, t.n_mixed, NR, NC, t.tot_word, t.zero_word, t.dump_word, t.big_word, t.conflict_cost_before, t.conflict_cost_after, t.conflict_floor})
         o.push_back(static_cast<uint16_t>(v));
     for (int v : t.ne) o.push_back(static_cast<uint16_t>(v));
     for (int v : t.nm) o.push_back(static_cast<uint16_t>(v));
@@ -620,15 +621,15 @@ inline std::vector<uint16_t> flatten_core_tables(const CoreTables& t) {
     return o;
 }
 inline bool unflatten_core_tables(const LdpcCode& c, const uint16_t* d, int n, CoreTables& t) {
-    if (n < 11) return false;
+    if (n < 12) return false;
     int p = 0;
     t = CoreTables{};
     t.k = c.k; t.m = c.m;
     t.ts = d[p++]; t.td = d[p++]; t.n_mixed = d[p++];
     const int NR = d[p++], NC = d[p++];
-    t.tot_word = d[p++]; t.zero_word = d[p++]; t.dump_word = d[p++];
+    t.tot_word = d[p++]; t.zero_word = d[p++]; t.dump_word = d[p++]; t.big_word = d[p++];
     t.conflict_cost_before = d[p++]; t.conflict_cost_after = d[p++]; t.conflict_floor = d[p++];
-    const long need = 11L + 2L * NR + NC + 64L * NR + 64L * NC + c.k + 64L * std::max(1, t.ts) + 64L * std::max(1, t.td);
+    const long need = 12L + 2L * NR + NC + 64L * NR + 64L * NC + c.k + 64L * std::max(1, t.ts) + 64L * std::max(1, t.td);
     if (NR != (c.m + 63) / 64 || NC != (c.k + 63) / 64 || need != n) return false;
     auto take = [&](std::vector<int>& v, int cnt) { v.assign(d + p, d + p + cnt); p += cnt; };
     auto take16 = [&](std::vector<uint16_t>& v, int cnt) { v.assign(d + p, d + p + cnt); p += cnt; };
@@ -646,7 +647,7 @@ inline bool validate_core_tables(const LdpcCode& c, const CoreTables& t) {
     for (int r = 0; r < NR; ++r) { if (t.nm[r] > t.ne[r] || t.ne[r] < 0) return false; row_off[r + 1] = row_off[r] + t.ne[r]; mixed += t.ne[r] - t.nm[r]; }
     for (int r = 0; r < NC; ++r) col_off[r + 1] = col_off[r] + t.dv[r];
     if (t.ts != row_off[NR] || t.td != col_off[NC] || t.n_mixed != mixed) return false;
-    if (t.tot_word != 64 * t.ts || t.zero_word != t.tot_word + 64 * NC || t.dump_word != t.zero_word + 64) return false;
+    if (t.tot_word != 64 * t.ts || t.zero_word != t.tot_word + 64 * NC || t.dump_word != t.zero_word + 64 || t.big_word != t.dump_word + 64) return false;
     if (static_cast<int>(t.check_at.size()) != 64 * NR || static_cast<int>(t.col_at.size()) != 64 * NC || static_cast<int>(t.col_pos.size()) != k) return false;
     if (static_cast<int>(t.row_addr.size()) != 64 * std::max(1, t.ts) || static_cast<int>(t.col_addr.size()) != 64 * std::max(1, t.td)) return false;
     std::vector<int> row_pos(m, -1), seen_col(k, 0);
@@ -670,14 +671,14 @@ inline bool validate_core_tables(const LdpcCode& c, const CoreTables& t) {
                 const int q = w - t.tot_word;
                 if (q < 0 || q >= 64 * NC || t.col_at[q] == 0xFFFF) return false;
                 got.push_back(t.col_at[q]);
-            } else if (w != t.zero_word + l) return false;
+            } else if (w != t.big_word + l) return false;
         }
         slot_col[i] = got;
         std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
         if (want != got) return false;
     }
     for (int r = 0; r < NR; ++r) for (int l = 0; l < 64; ++l) if (t.check_at[64 * r + l] == 0xFFFF)
-        for (int s = 0; s < t.ne[r]; ++s) if (t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l] != 4 * (t.zero_word + l)) return false;
+        for (int s = 0; s < t.ne[r]; ++s) if (t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l] != 4 * (t.big_word + l)) return false;
     for (int cr = 0; cr < NC; ++cr) for (int l = 0; l < 64; ++l) {
         const int cc = t.col_at[64 * cr + l] == 0xFFFF ? -1 : t.col_at[64 * cr + l];
         const int deg = cc < 0 ? 0 : static_cast<int>(col_checks[cc].size());

@@ -86,6 +86,12 @@ struct ShapeR56 {   // m = 108, k = 540
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 0, 0, 0, 0, 0}; return t[r]; }
 };
 
+// A padded slot of a mixed-degree round (a lane whose row has no edge there) gathers its "column total" from the lane's
+// big word: tot - c2v is then a positive magnitude no real message reaches (|LLR| <= 1e30 on entry, 50 afterwards), i.e.
+// the neutral element of the row's sign product and of its two smallest magnitudes, whatever the slot's own (unused)
+// c2v word holds.  Nothing is masked and nothing special is kept per iteration.
+constexpr float kPadTotal = 1.7e38f;
+
 template <class S>
 struct ShapeInfo {
     static constexpr int row_off(int r) { int t = 0; for (int i = 0; i < r; ++i) t += S::ne(i); return t; }   // x 64 words
@@ -97,7 +103,8 @@ struct ShapeInfo {
     static constexpr int tot_word = 64 * TS;           // column totals [64*NC]
     static constexpr int zero_word = tot_word + 64 * S::NC;   // 64 words of +0.0f (one per lane)
     static constexpr int dump_word = zero_word + 64;          // 64 write-only words (one per lane)
-    static constexpr int words = dump_word + 64;
+    static constexpr int big_word = dump_word + 64;           // 64 words of kPadTotal (one per lane): "column total" of a padded row slot
+    static constexpr int words = big_word + 64;
     // the same region doubles as mt19937 state + 648 normals during the retry cascade (>= 1296 words)
     static constexpr int lds_bytes = ((words < 1296 ? 1296 : words) * 4 + 15) & ~15;
 };
@@ -140,7 +147,6 @@ struct FastState {
     using I = ShapeInfo<S>;
     uint32_t rv[I::TS];            // gather addresses of the check pass
     uint32_t cs[I::TD > 0 ? I::TD : 1];   // gather addresses of the column pass
-    uint32_t keep[I::TM > 0 ? I::TM : 1]; // mixed slots: all ones on lanes that own an edge there, 0 on padded lanes
     float cv[I::TS];               // c2v of the row's own edges as written in the previous iteration (slots < NCV of fast_decode only)
     float li[S::NC];               // information-column LLRs (sorted position q = lane + 64 r)
     float lp[S::NR];               // identity-column LLRs (row position p = lane + 64 r)
@@ -165,18 +171,6 @@ __device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, con
     for (int i = 0; i < I::TS; ++i) { uint32_t a = base + c.row_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.rv[i] = a; }
 #pragma unroll
     for (int i = 0; i < I::TD; ++i) { uint32_t a = base + c.col_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.cs[i] = a; }
-    // mixed slots: a lane whose row has no edge there (its gather address points at the zero words) keeps
-    // -FLT_MAX as that edge's "previous c2v" for good: |0 - c2v| is then the neutral element of the row
-    // minimum (FLT_MAX in iteration 0, 50 = the clamp afterwards) with a positive sign
-    static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
-        constexpr int r = decltype(R_)::value;
-#pragma unroll
-        for (int s = S::nm(r); s < S::ne(r); ++s) {
-            uint32_t k = (c.row_addr[(I::row_off(r) + s) * 64 + lane] >= 4u * I::zero_word) ? 0u : 0xffffffffu;
-            asm volatile("" : "+v"(k));
-            st.keep[I::mix_off(r) + s - S::nm(r)] = k;
-        }
-    });
 }
 
 // store to LDS word (base/4 + OFF/4 + lane): ds_write_addtid_b32 takes its address from M0 + offset + 4*lane, needs
@@ -285,7 +279,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
                                   float factor, int max_iter, int lane, bool* ok) {
     using I = ShapeInfo<S>;
     const uint32_t lane4 = lds_addr(lds) + static_cast<uint32_t>(lane) * 4u;
-    const uint32_t kAbs = 0x7fffffffu, kSign = 0x80000000u, kNegMax = 0xff7fffffu;   // -FLT_MAX
+    const uint32_t kAbs = 0x7fffffffu;
     const uint32_t m0base = lds_addr(lds);
     // previous c2v := 0 (-FLT_MAX on the padded lanes of mixed slots), tot := channel LLR of the
     // information columns, zero words
@@ -293,7 +287,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
         constexpr int r = decltype(R_)::value;
 #pragma unroll
         for (int s = 0; s < S::ne(r); ++s) {
-            const float v0 = (s >= S::nm(r)) ? u2f(bfi(st.keep[I::mix_off(r) + (s >= S::nm(r) ? s - S::nm(r) : 0)], 0u, kNegMax)) : 0.0f;
+            const float v0 = 0.0f;
             if (I::row_off(r) + s < NCV) st.cv[I::row_off(r) + s] = v0;
             else lds_sf(lane4 + 256u * (I::row_off(r) + s), v0);
         }
@@ -301,6 +295,7 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
 #pragma unroll
     for (int r = 0; r < S::NC; ++r) lds_sf(lane4 + 4u * (I::tot_word + 64 * r), st.li[r]);
     lds_sf(lane4 + 4u * I::zero_word, 0.0f);
+    lds_sf(lane4 + 4u * I::big_word, kPadTotal);
 #pragma unroll
     for (int r = 0; r < S::NR; ++r) { st.pv[r] = st.lp[r]; st.pt[r] = 0.0f; }
     wave_sync();
@@ -358,8 +353,6 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             static_for<0, NE>([&](auto S_) __attribute__((always_inline)) {
                 constexpr int s = decltype(S_)::value;
                 uint32_t out = f2u(u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(v[s], min2, -min2))) * factor);
-                // padded lanes of a mixed slot keep -FLT_MAX as this edge's c2v
-                if constexpr (s >= S::nm(r)) out = bfi(st.keep[I::mix_off(r) + s - S::nm(r)], out, kNegMax);
                 lds_store_tid<256 * (off + s)>(m0base, u2f(out));
                 if constexpr (off + s < NCV) st.cv[off + s] = u2f(out);
             });

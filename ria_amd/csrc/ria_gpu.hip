@@ -142,7 +142,7 @@ static bool shape_fits(int rate, const CoreTables& t, int* wave_lds) {
         ok = static_cast<int>(t.ne.size()) == S::NR && static_cast<int>(t.dv.size()) == S::NC;
         for (int r = 0; ok && r < S::NR; ++r) ok = t.ne[r] == S::ne(r) && t.nm[r] == S::nm(r);
         for (int r = 0; ok && r < S::NC; ++r) ok = t.dv[r] == S::dv(r);
-        ok = ok && t.ts == I::TS && t.td == I::TD && t.tot_word == I::tot_word && t.zero_word == I::zero_word && t.dump_word == I::dump_word && t.n_mixed == I::TM && 4 * I::words <= 65536;
+        ok = ok && t.ts == I::TS && t.td == I::TD && t.tot_word == I::tot_word && t.zero_word == I::zero_word && t.dump_word == I::dump_word && t.big_word == I::big_word && t.n_mixed == I::TM && 4 * I::words <= 65536;
         *wave_lds = I::lds_bytes;
     });
     return ok;
