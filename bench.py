@@ -204,17 +204,17 @@ def main():
     # doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read; Infinity-Cache hits included).
     traffic, pmc_note, valu = None, None, None
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01n_hbm_traffic_pmc.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01o_hbm_traffic_pmc.json")))
         if B == 25000:
             stage = ["fast_primary_kernel", "fast_mark_kernel", "fast_stage_kernel", "fast_phase0_kernel", "fast_chain_kernel", "fast_cascade_kernel",
                      "fast_finalize_kernel", "frame_validate_kernel"] if t_decode >= t_demod else ["demod_frames_kernel"]
             traffic = int(sum(v["hbm_bytes_per_launch"] for k, v in tr.items() if any(n in k for n in stage)))
-            pmc_note = "profiles/r01n_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r01n_sq_utilisation_pmc.json")))
+            pmc_note = "profiles/r01o_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r01o_sq_utilisation_pmc.json")))
         c = sq.get("ria::fast_cascade_kernel<ria::ShapeR12>")
         if c:
             valu = {"kernel": "fast_cascade_kernel", "valu_busy_frac": c["valu_busy_frac"], "lds_busy_frac": c["lds_busy_frac"],
-                    "source": "profiles/r01n_sq_utilisation_pmc.json"}
+                    "source": "profiles/r01o_sq_utilisation_pmc.json"}
     except (OSError, ValueError, KeyError):
         pass
 
