@@ -111,6 +111,8 @@ typedef struct ria_decode_status {
 #define RIA_DECODE_CRC_RECOVER 0x4u  /* CRC-guided false-positive recovery (frame_v2.cpp:1564-1880) */
 #define RIA_DECODE_FULL        0x7u  /* exactly v2::decodeFixedFrame */
 #define RIA_DECODE_NO_CHANNEL_DEINTERLEAVE 0x100u
+#define RIA_RX_DEMOD_ONLY      0x200u  /* ria_gpu_rx_frames_host: process() + getSoftBits() only, no decode (info / decode
+                                          status pointers may be NULL, llr_out_host must not be) */
 
 typedef struct ria_gpu* ria_gpu_handle;
 
@@ -123,6 +125,14 @@ int  ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out);
 void ria_gpu_destroy(ria_gpu_handle h);
 const char* ria_gpu_last_error(ria_gpu_handle h);
 int  ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out);
+
+/* Execution knobs of a handle.  None of them changes a result; the parity tests run the fused call under every
+ * value and compare.
+ *   RIA_OPT_SPLIT_PARTS  ria_gpu_rx_batch cuts a batch of >= 4096 frames into this many parts that run on internal
+ *                        streams (1..4; 1 = one stream, no overlap; 0 = library default, which the environment
+ *                        variables RIA_SPLIT_PARTS / RIA_NO_SPLIT may override). */
+#define RIA_OPT_SPLIT_PARTS 1
+int  ria_gpu_set_option(ria_gpu_handle h, int option, int value);
 
 /* ---- RX: demodulate  (IWaveform::process + getSoftBits, waveform_interface.hpp:124,135;
  *          OFDMChirpWaveform::process ofdm_chirp_waveform.cpp:391-468) ------------------------- */
@@ -145,6 +155,14 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
                               float min_sum_factor, uint8_t* out_dev, uint8_t* ok_dev,
                               uint16_t* iters_dev, void* stream);
 
+/* robustDecodeSingleCW (src/gui/modem/streaming_decoder.cpp:1028-1058; the per-codeword decoder of the MC-DPSK and
+ * control-frame paths, :1290,:1454,:2620): a fresh LDPCDecoder at getRecommendedIterations(rate), min-sum factor
+ * 0.9375, then 0.875 / 0.75 / 0.625 / 0.5 until one converges.  n_cw rows of 648 LLRs in decoder order; out: n_cw *
+ * ceil(k/8) bytes (the last attempt's hard bits; the reference returns them only when ok); tries_dev (nullable):
+ * decodes made, 1..5; iters_dev: lastIterations() of the last one. */
+int ria_gpu_ldpc_decode_robust_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, uint8_t* out_dev, uint8_t* ok_dev,
+                                     uint16_t* iters_dev, uint8_t* tries_dev, void* stream);
+
 /* ---- RX: fused samples -> payload (process + getSoftBits + decodeFixedFrame in one pass) ------ */
 /* llr_out_dev and demod_status_dev may be NULL. */
 int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
@@ -152,7 +170,9 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
                      uint8_t* info_out_dev, ria_decode_status* decode_status_dev,
                      float* llr_out_dev, ria_frame_status* demod_status_dev, void* stream);
 
-/* Host-buffer convenience for the single-frame IWaveform adaptor (n_frames small). */
+/* Host-buffer forms for the single-frame IWaveform adaptor (n_frames small): the caller's buffers are ordinary host
+ * memory; the library stages them through a pinned + device block it keeps for the life of the handle (no allocation
+ * per call), runs on its own stream and returns when the results are in the caller's buffers. */
 int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ria_frame_meta* meta_host,
                            int n_frames, uint32_t flags, uint8_t* info_out_host,
                            ria_decode_status* decode_status_host, float* llr_out_host,

@@ -170,6 +170,118 @@ def lts_fixture(R, O):
     return {"buffers": np.stack([x for x, _ in bufs]), "cfo": np.array([c for _, c in bufs], np.float32), "results": np.stack(res)}
 
 
+# (mod, rate, burst frames N, lead samples, channel kind, snr dB, cfo Hz (applied from sample 0, known to the receiver),
+#  abs_base, marker transmitted)
+BURST_CASES = [(po.QAM16, po.R1_2, 3, 1777, 0, 22.0, 0.0, 0, 1), (po.QAM16, po.R1_2, 4, 0, 2, 20.0, 0.0, 0, 1),
+               (po.QAM16, po.R1_2, 2, 2600, 0, 18.0, 3.0, 4800, 1), (po.DQPSK, po.R1_2, 4, 900, 1, 15.0, 0.0, 0, 1),
+               (po.QAM16, po.R1_2, 3, 1234, 0, 22.0, 0.0, 0, 0), (po.QAM64, po.R3_4, 8, 500, 0, 28.0, -2.0, 96000, 1),
+               (po.QAM16, po.R1_2, 4, 3100, 2, 14.0, 0.0, 0, 1)]
+BURST_BPC = {po.R1_4: 20, po.R1_2: 40, po.R2_3: 54, po.R3_4: 60, po.R5_6: 67}
+
+
+def burst_buffer(O, case, idx):
+    """One burst-interleaved group as the air interface carries it, rebuilt from the recipe with the oracle's TX pieces
+    (each pinned bit-for-bit to the reference): N serialized frames -> encodeFixedFrame -> BurstInterleaver::interleave
+    -> [2 LTS][data] per frame, first LTS of the group negated (streaming_encoder.cpp:302-389); scaled to peak 0.5,
+    `lead` samples of silence in front, 3000 behind, optional CFO (analytic rotation from sample 0), channel over the
+    whole capture.  -> (rx buffer float32, info bytes [N, 4*bpc], crc32 of the buffer)"""
+    import zlib
+    mod, rate, n, lead, kind, snr, cfo, abs_base, marker = case
+    rng = np.random.default_rng(31000 + idx)
+    bpc = BURST_BPC[rate]
+    infos = np.stack([O.make_frame(rng.integers(0, 256, 4 * bpc - 19, dtype=np.uint8), 500 + 10 * idx + f, rate) for f in range(n)])
+    g = O.geom(mod, rate)
+    coded = np.stack([O.encode_fixed_frame(infos[f], rate, True, g.bits_per_symbol) for f in range(n)])
+    phys = O.burst_interleave(coded) if n >= 2 else coded
+    frames = []
+    for f in range(n):
+        a = O.modulate(mod, rate, phys[f])
+        if f == 0 and marker:
+            a[:1152] = -a[:1152]
+        frames.append(a)
+    s = np.concatenate(frames)
+    s = s * np.float32(0.5 / np.abs(s).max())
+    x = np.concatenate([np.zeros(lead, np.float32), s, np.zeros(3000, np.float32)])
+    if cfo:
+        n_all = len(x)
+        spec = np.fft.fft(x.astype(np.float64))
+        h = np.zeros(n_all); h[0] = 1; h[1:(n_all + 1) // 2] = 2
+        if n_all % 2 == 0:
+            h[n_all // 2] = 1
+        x = np.real(np.fft.ifft(spec * h) * np.exp(2j * np.pi * cfo * (abs_base + np.arange(n_all)) / 48000.0)).astype(np.float32)
+    x = O.channel(kind, snr, 7100 + idx, x)
+    return x, infos, zlib.crc32(x.tobytes())
+
+
+def burst_fixture(R, O):
+    """8f-3 + a9: burst groups through ONE reference waveform object in StreamingDecoder's call order
+    (oracle/ref_shim.cpp ref_burst_rx), and the reference's own TX of the first case (pins the recipe's TX pieces)."""
+    rec = {"cases": np.array(BURST_CASES, np.float64)}
+    for i, case in enumerate(BURST_CASES):
+        mod, rate, n, lead, kind, snr, cfo, abs_base, marker = case
+        x, infos, crc = burst_buffer(O, case, i)
+        s_ref, cl, cp = R.burst_tx(mod, rate, infos, bool(marker))
+        coded = np.stack([O.encode_fixed_frame(infos[f], rate, True, O.geom(mod, rate).bits_per_symbol) for f in range(n)])
+        assert np.array_equal(cl, coded) and np.array_equal(cp, O.burst_interleave(coded) if n >= 2 else coded)
+        frames = np.concatenate([O.modulate(mod, rate, cp[f]) for f in range(n)])
+        if marker:
+            frames[:1152] = -frames[:1152]
+        assert np.array_equal(frames.view(np.uint32), s_ref.view(np.uint32)), "oracle TX pieces != reference burst TX"
+        r = R.burst_rx(mod, rate, x, n, known_cfo=float(cfo), abs_base=int(abs_base), bpc=BURST_BPC[rate])
+        assert r["n_soft"] > 0, (i, r["n_soft"])
+        rec[f"crc_{i}"] = np.array([crc], np.uint32)
+        rec[f"infos_{i}"] = infos
+        for k in ("sync", "llr", "cfo_used", "cfo_after", "logical", "dec_data", "dec_ok"):
+            rec[f"{k}_{i}"] = r[k]
+        print("burst case", i, "sync", r["sync"], "cfo_after", r["cfo_after"], "frames decoded", r["dec_ok"].all(axis=1).astype(int),
+              "== tx", [(r["dec_data"][f] == infos[f]).all() for f in range(n)])
+    return rec
+
+
+def burst_interleaver_fixture(R):
+    """fec::BurstInterleaver permutations recorded from the reference: random coded bytes in, physical bytes out, and
+    the soft-bit de-interleave as an index map (physical flat index of every logical position)."""
+    rng = np.random.default_rng(808)
+    rec = {}
+    for n in (1, 2, 3, 4, 7, 8):
+        lb = rng.integers(0, 256, (n, 324), dtype=np.uint8)
+        rec[f"logical_bytes_{n}"] = lb
+        rec[f"physical_bytes_{n}"] = R.burst_interleave(lb)
+        probe = np.arange(n * 2592, dtype=np.float32).reshape(n, 2592)
+        rec[f"deint_index_{n}"] = R.burst_deinterleave(probe).astype(np.int32)
+    return rec
+
+
+def robust_fixture(R):
+    """robustDecodeSingleCW (streaming_decoder.cpp:1028-1058) on noisy codewords at the edge of convergence, so that
+    every number of tries 1..5 and the all-fail outcome occur: ok, tries, iterations, bytes recorded from the reference."""
+    rng = np.random.default_rng(60606)
+    rec = {}
+    for rate, sig in ((po.R1_4, (1.3, 1.4, 1.5)), (po.R1_2, (0.8, 0.84, 0.88)), (po.R3_4, (0.5, 0.53, 0.56))):
+        k = {po.R1_4: 162, po.R1_2: 324, po.R3_4: 486}[rate]
+        llrs, res = [], []
+        for t in range(3000):
+            info = rng.integers(0, 256, (k + 7) // 8, dtype=np.uint8)
+            if k % 8:
+                info[-1] &= (0xFF << (8 - k % 8)) & 0xFF
+            bits = np.unpackbits(R.ldpc_encode(rate, info)[:81])[:648].astype(np.float32)
+            sigma = sig[t % 3]
+            llr = np.clip(((1.0 - 2.0 * bits) + rng.normal(0, sigma, 648)) * (2.0 / sigma ** 2), -20, 20).astype(np.float32)
+            ok, out, it, tries = R.robust_decode(rate, llr)
+            llrs.append(llr)
+            res.append(np.concatenate([[int(ok), tries, it], out[:(k + 7) // 8]]).astype(np.int32))
+        res = np.stack(res)
+        # keep the interesting ones: every retry outcome, plus a few plain successes and failures
+        keep = []
+        for tries in (1, 2, 3, 4, 5):
+            keep += [i for i in range(len(res)) if res[i, 1] == tries and res[i, 0] == 1][:8]
+        keep += [i for i in range(len(res)) if res[i, 0] == 0][:8]
+        rec[f"llr_{rate}"] = np.stack(llrs)[keep]
+        rec[f"res_{rate}"] = res[keep]
+        print("robust rate", rate, "tries histogram", np.bincount(res[keep][:, 1], minlength=6), "ok", int(res[keep][:, 0].sum()), "of", len(keep))
+    return rec
+
+
 def chirp_fixture(R):
     chirp = R.chirp_generate()
     rec = {"preamble_crc": np.array([__import__("zlib").crc32(chirp.tobytes())], np.uint32), "cases": np.array(CHIRP_CASES, np.float32)}
@@ -226,6 +338,13 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"frames_{name}.npz"), **rec)
         print(name, "frames", len(chans), "decoded", [int(o.all()) for o in L["dec_ok"]])
 
+    if only == "robust":
+        np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
+        return 0
+    if only == "burst":
+        np.savez_compressed(os.path.join(OUT, "burst_chain.npz"), **burst_fixture(R, O))
+        np.savez_compressed(os.path.join(OUT, "burst_interleaver.npz"), **burst_interleaver_fixture(R))
+        return 0
     if only:
         return 0
     # ---- raw LDPC vectors per rate (encode + decode with iteration counts)
@@ -292,6 +411,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "mcdpsk.npz"), **mcdpsk_fixture(R))
     np.savez_compressed(os.path.join(OUT, "lts_sync.npz"), **lts_fixture(R, O))
     np.savez_compressed(os.path.join(OUT, "cox_sync.npz"), **cox_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "burst_chain.npz"), **burst_fixture(R, O))
+    np.savez_compressed(os.path.join(OUT, "burst_interleaver.npz"), **burst_interleaver_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
     print("done ->", OUT)
     return 0
 

@@ -73,6 +73,12 @@ class Oracle:
         self.lib = L = C.CDLL(build_oracle())
         L.ro_rx_process.argtypes = [C.POINTER(Geom), _f, C.c_int, C.c_float, C.c_longlong, _f, C.c_int,
                                     C.POINTER(RxAux)]
+        L.ro_rx_process_flags.argtypes = [C.POINTER(Geom), _f, C.c_int, C.c_float, C.c_longlong, C.c_int, _f, C.c_int,
+                                          C.POINTER(RxAux)]
+        L.ro_burst_interleave.argtypes = [C.c_int, _u8, _u8]
+        L.ro_burst_interleave.restype = None
+        L.ro_burst_deinterleave.argtypes = [C.c_int, _f, C.c_int, _f]
+        L.ro_burst_deinterleave.restype = None
         L.ro_channel.argtypes = [C.c_int, C.c_float, C.c_uint32, _f, C.c_int, _f]
         L.ro_ldpc_decode.argtypes = [C.POINTER(Ldpc), _f, C.c_int, C.c_int, C.c_float, _u8, _i]
         L.ro_decode_fixed_frame.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8, _u8, _i, _i]
@@ -202,14 +208,28 @@ class Oracle:
         self.lib.ro_channel(kind, snr_db, seed, fp(x), len(x), fp(y))
         return y
 
-    def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0):
+    def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0, burst_marker=False):
         g = self.geom(mod, rate)
         samples = np.ascontiguousarray(samples, np.float32)
         llr = np.zeros(8 * NCAR * 64, np.float32)
         aux = RxAux()
-        n = self.lib.ro_rx_process(C.byref(g), fp(samples), len(samples), cfo_hz, abs_pos, fp(llr), len(llr),
-                                   C.byref(aux))
+        n = self.lib.ro_rx_process_flags(C.byref(g), fp(samples), len(samples), cfo_hz, abs_pos, int(bool(burst_marker)),
+                                         fp(llr), len(llr), C.byref(aux))
         return llr[:n].copy(), aux
+
+    def burst_interleave(self, logical):
+        """[N, 324] coded bytes -> physical [N, 324] (fec::BurstInterleaver::interleave)"""
+        logical = np.ascontiguousarray(logical, np.uint8)
+        out = np.zeros_like(logical)
+        self.lib.ro_burst_interleave(logical.shape[0], up(logical), up(out))
+        return out
+
+    def burst_deinterleave(self, physical):
+        """[N, >=2592] soft bits of the physical frames -> logical [N, 2592] (BurstInterleaver::deinterleave)"""
+        physical = np.ascontiguousarray(physical, np.float32)
+        out = np.zeros((physical.shape[0], 2592), np.float32)
+        self.lib.ro_burst_deinterleave(physical.shape[0], fp(physical), physical.shape[1], fp(out))
+        return out
 
     def ldpc_encode(self, rate, info):
         c = self.code(rate)
@@ -225,6 +245,18 @@ class Oracle:
         it = C.c_int()
         ok = self.lib.ro_ldpc_decode(C.byref(c), fp(llr), len(llr), max_iter, factor, up(out), C.byref(it))
         return bool(ok), out[:(c.k + 7) // 8].copy(), it.value
+
+    def robust_decode(self, rate, llr):
+        """robustDecodeSingleCW (streaming_decoder.cpp:1028-1058) restated on the oracle's decoder:
+        -> (ok, bytes of the last attempt, iterations, tries)"""
+        mi = self.geom(QAM16, rate).max_iter          # getRecommendedIterations (ldpc_codec.hpp:86-95)
+        ok, out, it, tries = False, None, 0, 0
+        for factor in (0.9375, 0.875, 0.75, 0.625, 0.5):
+            ok, out, it = self.ldpc_decode(rate, llr, mi, factor)
+            tries += 1
+            if ok:
+                break
+        return ok, out, it, tries
 
     def decode_fixed_frame(self, llr, rate, ch_deint, bps, flags=3):
         g = self.geom(QAM16, rate)
@@ -269,6 +301,13 @@ class Ref:
         L.ref_cox_transmit.argtypes = [C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
         L.ref_cox_lts_template.argtypes = [C.c_int, C.c_int, _f, _f]
         L.ref_cox_rx.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, _f, _f, C.c_int, _f]
+        _i64 = C.c_longlong
+        L.ref_robust_decode.argtypes = [C.c_int, _f, C.c_int, _u8, C.c_int, _i, _i]
+        L.ref_burst_tx.argtypes = [C.c_int, C.c_int, _u8, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, _u8, _u8]
+        L.ref_burst_rx.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _i64, _f, _f, C.c_int,
+                                   _f, _f, _f, _u8, _u8]
+        L.ref_burst_interleave.argtypes = [C.c_int, _u8, _u8]
+        L.ref_burst_deinterleave.argtypes = [C.c_int, _f, _f]
         L.ref_quiet()
 
     def cox_search(self, samples, threshold=0.8, noise_floor=0.0, mod=QAM16, rate=R1_2):
@@ -297,6 +336,44 @@ class Ref:
         tI, tQ = np.zeros(1152, np.float32), np.zeros(1152, np.float32)
         assert self.lib.ref_cox_lts_template(mod, rate, fp(tI), fp(tQ)) == 1152
         return tI, tQ
+
+    def burst_interleave(self, logical):
+        logical = np.ascontiguousarray(logical, np.uint8)
+        out = np.zeros_like(logical)
+        self.lib.ref_burst_interleave(logical.shape[0], up(logical), up(out))
+        return out
+
+    def burst_deinterleave(self, physical):
+        physical = np.ascontiguousarray(physical[:, :2592], np.float32)
+        out = np.zeros_like(physical)
+        self.lib.ref_burst_deinterleave(physical.shape[0], fp(physical), fp(out))
+        return out
+
+    def burst_tx(self, mod, rate, infos, negate_first_lts=True):
+        """One burst group as StreamingEncoder::encodeBurstLight builds it: infos uint8 [N, info_bytes] ->
+        (samples, coded logical [N,324], coded physical [N,324])"""
+        infos = np.ascontiguousarray(infos, np.uint8)
+        n = infos.shape[0]
+        out = np.zeros(n * 60000, np.float32)
+        cl, cp = np.zeros((n, 324), np.uint8), np.zeros((n, 324), np.uint8)
+        m = self.lib.ref_burst_tx(mod, rate, up(infos), infos.shape[1], infos.shape[1], n, int(negate_first_lts), fp(out), len(out),
+                                  up(cl), up(cp))
+        assert m > 0, m
+        return out[:m].copy(), cl, cp
+
+    def burst_rx(self, mod, rate, samples, n_frames, known_cfo=0.0, threshold=0.5, search_len=21000, abs_base=0, bpc=40):
+        """One burst group through ONE OFDMChirpWaveform in StreamingDecoder's call order -> dict"""
+        x = np.ascontiguousarray(samples, np.float32)
+        sync4 = np.zeros(4, np.float32)
+        llr = np.zeros((n_frames, 4096), np.float32)
+        cfo_used, cfo_after = np.zeros(n_frames, np.float32), np.zeros(n_frames, np.float32)
+        logical = np.zeros((n_frames, 2592), np.float32)
+        dec = np.zeros((n_frames, 4 * bpc), np.uint8)
+        ok = np.zeros((n_frames, 4), np.uint8)
+        m = self.lib.ref_burst_rx(mod, rate, fp(x), len(x), search_len, n_frames, known_cfo, threshold, abs_base, fp(sync4), fp(llr),
+                                  llr.shape[1], fp(cfo_used), fp(cfo_after), fp(logical), up(dec), up(ok))
+        return {"n_soft": m, "sync": sync4, "llr": llr[:, :max(m, 0)].copy(), "cfo_used": cfo_used, "cfo_after": cfo_after,
+                "logical": logical, "dec_data": dec, "dec_ok": ok}
 
     def zc_generate(self, root):
         out = np.zeros(4096, np.float32)
@@ -393,6 +470,14 @@ class Ref:
         it = C.c_int()
         n = self.lib.ref_ldpc_decode(rate, fp(llr), len(llr), max_iter, factor, up(out), 256, C.byref(it))
         return n > 0, out[:abs(n)].copy(), it.value
+
+    def robust_decode(self, rate, llr):
+        """robustDecodeSingleCW -> (ok, bytes of the last attempt, iterations, tries)"""
+        llr = np.ascontiguousarray(llr, np.float32)
+        out = np.zeros(256, np.uint8)
+        it, tr = C.c_int(), C.c_int()
+        n = self.lib.ref_robust_decode(rate, fp(llr), len(llr), up(out), 256, C.byref(it), C.byref(tr))
+        return n > 0, out[:abs(n)].copy(), it.value, tr.value
 
     def decode_fixed_frame(self, llr, rate, ch_deint, bps):
         llr = np.ascontiguousarray(llr, np.float32)

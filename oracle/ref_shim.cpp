@@ -232,6 +232,31 @@ int ref_ldpc_decode(int rate, const float* llr, int n, int max_iter, float facto
     return dec.lastDecodeSuccess() ? static_cast<int>(b.size()) : -static_cast<int>(b.size());
 }
 
+// robustDecodeSingleCW is a file-static function of streaming_decoder.cpp (:1028-1058); these are its statements on
+// the reference's own LDPCDecoder: recommended iterations, factor 0.9375, then 0.875 / 0.75 / 0.625 / 0.5.
+int ref_robust_decode(int rate, const float* llr, int n, uint8_t* out, int max_out, int* iters, int* tries) {
+    CodeRate cr = static_cast<CodeRate>(rate);
+    LDPCDecoder decoder(cr);
+    decoder.setMaxIterations(fec::LDPCCodec::getRecommendedIterations(cr));
+    decoder.setMinSumFactor(0.9375f);
+    auto decoded = decoder.decodeSoft(std::span<const float>(llr, n));
+    bool ok = decoder.lastDecodeSuccess();
+    int t = 1;
+    if (!ok) {
+        static constexpr float factors[] = {0.875f, 0.75f, 0.625f, 0.5f};
+        for (int retry = 0; retry < 4 && !ok; retry++) {
+            decoder.setMinSumFactor(factors[retry]);
+            decoded = decoder.decodeSoft(std::span<const float>(llr, n));
+            ok = decoder.lastDecodeSuccess();
+            ++t;
+        }
+    }
+    std::memcpy(out, decoded.data(), std::min<size_t>(decoded.size(), max_out));
+    if (iters) *iters = decoder.lastIterations();
+    if (tries) *tries = t;
+    return ok ? static_cast<int>(decoded.size()) : -static_cast<int>(decoded.size());
+}
+
 int ref_ldpc_encode(int rate, const uint8_t* in, int n, uint8_t* out, int max_out) {
     LDPCEncoder enc(static_cast<CodeRate>(rate));
     Bytes b = enc.encode(ByteSpan(in, n));
@@ -447,6 +472,103 @@ int ref_burst_deinterleave(int n_frames, const float* physical, float* logical) 
     auto out = fec::BurstInterleaver::deinterleave(in);
     for (int f = 0; f < n_frames; ++f) std::memcpy(logical + f * 2592, out[f].data(), 2592 * sizeof(float));
     return 0;
+}
+
+// ---------------------------------------------------------------- burst chain
+// TX of one burst-interleaved group as StreamingEncoder::encodeBurstLight builds it (streaming_encoder.cpp:302-389):
+// every frame LDPC-encoded + frame/channel-interleaved (encodeFixedFrame), the group byte-interleaved
+// (BurstInterleaver::interleave), then [data preamble][modulated frame] per frame with the first LTS symbol of the
+// group's first frame negated.  info: n_frames * info_stride bytes (serialized frames); returns the sample count.
+int ref_burst_tx(int mod, int rate, const uint8_t* info, int info_stride, int n_info, int n_frames, int negate_first_lts,
+                 float* samples_out, int max_samples, uint8_t* coded_logical_out, uint8_t* coded_physical_out) {
+    ref_quiet();
+    ModemConfig cfg = named_config(mod, rate);
+    OFDMChirpWaveform tx(cfg);
+    tx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    CodeRate cr = static_cast<CodeRate>(rate);
+    int pilots = (cfg.num_carriers + tx.config_.pilot_spacing - 1) / tx.config_.pilot_spacing;
+    size_t bps = (cfg.num_carriers - pilots) * getBitsPerSymbol(static_cast<Modulation>(mod));
+    std::vector<Bytes> encoded;
+    for (int f = 0; f < n_frames; ++f) {
+        Bytes fd(info + static_cast<size_t>(f) * info_stride, info + static_cast<size_t>(f) * info_stride + n_info);
+        encoded.push_back(protocol::v2::encodeFixedFrame(fd, cr, true, bps));
+        if (coded_logical_out) std::memcpy(coded_logical_out + f * 324, encoded.back().data(), 324);
+    }
+    if (n_frames >= 2) encoded = fec::BurstInterleaver::interleave(encoded);
+    std::vector<float> result;
+    for (int f = 0; f < n_frames; ++f) {
+        if (coded_physical_out) std::memcpy(coded_physical_out + f * 324, encoded[f].data(), 324);
+        Samples pre = tx.generateDataPreamble();
+        if (f == 0 && negate_first_lts) for (size_t j = 0; j < pre.size() / 2; ++j) pre[j] = -pre[j];
+        Samples dat = tx.modulate(encoded[f]);
+        result.insert(result.end(), pre.begin(), pre.end());
+        result.insert(result.end(), dat.begin(), dat.end());
+    }
+    int n = static_cast<int>(result.size());
+    if (n > max_samples) return -n;
+    std::memcpy(samples_out, result.data(), result.size() * sizeof(float));
+    return n;
+}
+
+// RX of one burst group on ONE waveform object in the order gui::StreamingDecoder drives it:
+//   detectDataSync(search span)                                           streaming_decoder.cpp:723-733
+//   setAbsoluteTrainingPosition(abs_base + start), setFrequencyOffset     :896, :1347
+//   process(first frame)  [consumes the one-shot marker], getSoftBits     :1350-1363
+//   wasBurstInterleaved() AFTER process() -> accumulation                 :1380-1407
+//   per continuation frame: setFrequencyOffset(burst_cfo), process(block at burst_next_pos_), getSoftBits,
+//   estimatedCFO with the 2 Hz drift clamp                                :3127-3208
+//   BurstInterleaver::deinterleave + decodeFixedFrame per logical frame   :3210-3240 (decodeFrame :2821)
+// sync4 = {detected, start_sample, correlation, marker latched AFTER the first process()}; cfo_used[f] is the CFO
+// handed to setFrequencyOffset before frame f; cfo_after[f] = estimatedCFO() after it.  Returns soft bits per frame.
+int ref_burst_rx(int mod, int rate, const float* samples, int n, int search_len, int n_frames, float known_cfo, float thr,
+                 long long abs_base, float* sync4, float* llr_out, int llr_stride, float* cfo_used, float* cfo_after,
+                 float* logical_out, uint8_t* dec_data, uint8_t* dec_ok) {
+    ref_quiet();
+    ModemConfig cfg = named_config(mod, rate);
+    OFDMChirpWaveform rx(cfg);
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    CodeRate cr = static_cast<CodeRate>(rate);
+    int pilots = (cfg.num_carriers + rx.config_.pilot_spacing - 1) / rx.config_.pilot_spacing;
+    size_t bps = (cfg.num_carriers - pilots) * getBitsPerSymbol(static_cast<Modulation>(mod));
+    SyncResult r;
+    bool ok = rx.detectDataSync(SampleSpan(samples, std::min(n, search_len)), r, known_cfo, thr);
+    sync4[0] = ok ? 1.f : 0.f; sync4[1] = static_cast<float>(r.start_sample); sync4[2] = r.correlation; sync4[3] = 0.f;
+    if (!ok) return 0;
+    const size_t frame_len = static_cast<size_t>(rx.getMinSamplesForFrame());
+    size_t pos = static_cast<size_t>(r.start_sample);
+    if (pos + frame_len * n_frames > static_cast<size_t>(n)) return -1;
+    rx.setAbsoluteTrainingPosition(static_cast<size_t>(abs_base) + pos);
+    float burst_cfo = known_cfo;
+    std::vector<std::vector<float>> soft_buffer;
+    int n_soft = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        rx.setFrequencyOffset(burst_cfo);
+        cfo_used[f] = burst_cfo;
+        if (!rx.process(SampleSpan(samples + pos, frame_len))) return -2 - f;
+        std::vector<float> soft = rx.getSoftBits();
+        if (f == 0) sync4[3] = rx.wasBurstInterleaved() ? 1.f : 0.f;
+        n_soft = static_cast<int>(soft.size());
+        std::memcpy(llr_out + static_cast<size_t>(f) * llr_stride, soft.data(), std::min(n_soft, llr_stride) * sizeof(float));
+        float corrected = rx.estimatedCFO();
+        cfo_after[f] = corrected;
+        float drift = corrected - burst_cfo;                       // MAX_(PILOT|BURST)_CFO_DRIFT_HZ = 2.0
+        if (std::abs(drift) > 2.0f) corrected = burst_cfo + std::copysign(2.0f, drift);
+        burst_cfo = corrected;
+        soft_buffer.push_back(std::move(soft));
+        pos += frame_len;
+    }
+    auto logical = fec::BurstInterleaver::deinterleave(soft_buffer);
+    size_t bpc = protocol::v2::getBytesPerCodeword(cr);
+    for (int f = 0; f < n_frames; ++f) {
+        std::memcpy(logical_out + static_cast<size_t>(f) * 2592, logical[f].data(), 2592 * sizeof(float));
+        auto st = protocol::v2::decodeFixedFrame(logical[f], cr, true, bps);
+        for (int cw = 0; cw < 4; ++cw) {
+            dec_ok[f * 4 + cw] = st.decoded[cw] ? 1 : 0;
+            std::memset(dec_data + (static_cast<size_t>(f) * 4 + cw) * bpc, 0, bpc);
+            if (st.decoded[cw] && st.data[cw].size() >= bpc) std::memcpy(dec_data + (static_cast<size_t>(f) * 4 + cw) * bpc, st.data[cw].data(), bpc);
+        }
+    }
+    return n_soft;
 }
 
 }  // extern "C"

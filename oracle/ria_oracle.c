@@ -1128,9 +1128,25 @@ static int ro_demod_symbol(ro_rx* r, const cf* eq, float* soft) { /* demodulator
 
 int ro_rx_process(const ro_geom* g, const float* samples, int n, float cfo_hz, long long abs_pos,
                   float* llr_out, int max_llr, ro_rx_aux* aux) {
+    return ro_rx_process_flags(g, samples, n, cfo_hz, abs_pos, 0, llr_out, max_llr, aux);
+}
+
+int ro_rx_process_flags(const ro_geom* g, const float* samples_in, int n, float cfo_hz, long long abs_pos, int flags,
+                        float* llr_out, int max_llr, ro_rx_aux* aux) {
     /* OFDMChirpWaveform::process (ofdm_chirp_waveform.cpp:391-468) +
      * OFDMDemodulator::processPresynced (demodulator.cpp:1250-1414) */
     if (n < RO_SYM) return 0;
+    /* flags bit0 = burst_interleaved_detected_: the first LTS symbol (getSamplesPerSymbol() samples, cyclic prefix
+     * included) is negated on a copy before the demodulator sees it (ofdm_chirp_waveform.cpp:421-440) */
+    const float* samples = samples_in;
+    float* modified = NULL;
+    if (flags & 1) {
+        modified = (float*)malloc((size_t)n * sizeof(float));
+        if (!modified) return 0;
+        memcpy(modified, samples_in, (size_t)n * sizeof(float));
+        for (int i = 0; i < RO_SYM && i < n; ++i) modified[i] = -modified[i];
+        samples = modified;
+    }
     static _Thread_local ro_rx r;
     memset(&r, 0, sizeof(r));
     r.g = g;
@@ -1171,7 +1187,30 @@ int ro_rx_process(const ro_geom* g, const float* samples, int n, float cfo_hz, l
         aux->snr_symbol_count = (float)r.snr_count;
         for (int l = 0; l < RO_NCAR; ++l) { aux->h[2 * l] = r.H[g->all_idx[l]].re; aux->h[2 * l + 1] = r.H[g->all_idx[l]].im; }
     }
+    free(modified);
     return r.n_soft;
+}
+
+/* fec::BurstInterleaver (src/fec/burst_interleaver.cpp:8-78): N frames of 324 coded bytes / 2592 soft bits.
+ * TX: physical[(N*b+f)/324][(N*b+f)%324] = logical[f][b]; RX: the 8 soft bits of every byte travel together.
+ * N < 2 copies (burst_interleaver.cpp:12,45). */
+void ro_burst_interleave(int n_frames, const uint8_t* logical, uint8_t* physical) {
+    const int B = 324;
+    if (n_frames < 2) { memcpy(physical, logical, (size_t)(n_frames > 0 ? n_frames : 0) * B); return; }
+    for (int f = 0; f < n_frames; ++f)
+        for (int b = 0; b < B; ++b) {
+            const int flat = n_frames * b + f;
+            physical[(flat / B) * B + flat % B] = logical[f * B + b];
+        }
+}
+void ro_burst_deinterleave(int n_frames, const float* physical, int stride, float* logical /* [n_frames][2592] */) {
+    const int B = 324, BITS = 2592;
+    for (int f = 0; f < n_frames; ++f)
+        for (int b = 0; b < B; ++b) {
+            const int flat = n_frames * b + f;
+            const int pf = n_frames < 2 ? f : flat / B, pb = n_frames < 2 ? b : flat % B;
+            for (int bit = 0; bit < 8; ++bit) logical[f * BITS + 8 * b + bit] = physical[(size_t)pf * stride + 8 * pb + bit];
+        }
 }
 
 /* ------------------------------------------------------------------ decodeFixedFrame */

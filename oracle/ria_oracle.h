@@ -91,6 +91,14 @@ typedef struct ro_rx_aux {
 int ro_rx_process(const ro_geom* g, const float* samples, int n, float cfo_hz, long long abs_pos,
                   float* llr_out, int max_llr, ro_rx_aux* aux);
 
+/* the same with OFDMChirpWaveform's one-shot burst marker: flags bit0 = the first LTS symbol was negated on air
+ * (ofdm_chirp_waveform.cpp:421-440) */
+int ro_rx_process_flags(const ro_geom* g, const float* samples, int n, float cfo_hz, long long abs_pos, int flags,
+                        float* llr_out, int max_llr, ro_rx_aux* aux);
+/* fec::BurstInterleaver (src/fec/burst_interleaver.cpp:8-78) */
+void ro_burst_interleave(int n_frames, const uint8_t* logical, uint8_t* physical);
+void ro_burst_deinterleave(int n_frames, const float* physical, int stride, float* logical);
+
 /* ---- decode (src/protocol/frame_v2.cpp:1335-1883) */
 /* flags bit0: run retry cascade phase 0; bit1: phases 1-6; bit2: CRC false-positive recovery */
 int ro_decode_fixed_frame(const float* llr, int n, int rate, int ch_deint, int bps, int flags,

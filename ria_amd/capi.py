@@ -10,11 +10,13 @@ MOD = {"DBPSK": 0, "BPSK": 1, "DQPSK": 2, "QPSK": 3, "D8PSK": 4, "QAM16": 6, "QA
 RATE = {"R1_4": 0, "R1_3": 1, "R1_2": 2, "R2_3": 3, "R3_4": 4, "R5_6": 5}
 DECODE_PHASE0, DECODE_PERTURB, DECODE_CRC_RECOVER, DECODE_FULL = 1, 2, 4, 7
 DECODE_NO_CHANNEL_DEINTERLEAVE = 0x100
+RX_DEMOD_ONLY = 0x200
+OPT_SPLIT_PARTS = 1
 
 # every symbol include/ria_gpu.h declares
 EXPORTS = [
     "ria_gpu_abi_version", "ria_gpu_default_config", "ria_gpu_create", "ria_gpu_destroy", "ria_gpu_last_error",
-    "ria_gpu_get_geometry", "ria_gpu_demod_batch", "ria_gpu_decode_batch", "ria_gpu_ldpc_decode_batch",
+    "ria_gpu_get_geometry", "ria_gpu_set_option", "ria_gpu_demod_batch", "ria_gpu_decode_batch", "ria_gpu_ldpc_decode_batch", "ria_gpu_ldpc_decode_robust_batch",
     "ria_gpu_rx_batch", "ria_gpu_rx_frames_host", "ria_gpu_decode_frames_host", "ria_gpu_tx_batch", "ria_gpu_make_frames",
     "ria_gpu_channel_batch", "ria_gpu_channel_exact_batch", "ria_gpu_debug_math", "ria_gpu_sync_zc_batch", "ria_gpu_zc_preamble", "ria_gpu_sync_chirp_batch", "ria_gpu_chirp_preamble", "ria_gpu_mcdpsk_demod_batch",
     "ria_gpu_mcdpsk_modulate_host", "ria_gpu_chase_combine_batch", "ria_gpu_sync_lts_batch", "ria_gpu_sync_host", "ria_gpu_ldpc_encode_host", "ria_gpu_burst_deinterleave_batch", "ria_gpu_burst_interleave_batch",
@@ -91,9 +93,11 @@ def load(build_if_needed=True):
     L.ria_gpu_last_error.argtypes = [vp]
     L.ria_gpu_last_error.restype = C.c_char_p
     L.ria_gpu_get_geometry.argtypes = [vp, C.POINTER(Geometry)]
+    L.ria_gpu_set_option.argtypes = [vp, i32, i32]
     L.ria_gpu_demod_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.ria_gpu_decode_batch.argtypes = [vp, vp, i32, i32, u32, vp, vp, vp]
     L.ria_gpu_ldpc_decode_batch.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp]
+    L.ria_gpu_ldpc_decode_robust_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.ria_gpu_rx_batch.argtypes = [vp, vp, vp, vp, i32, u32, vp, vp, vp, vp, vp]
     L.ria_gpu_rx_frames_host.argtypes = [vp, vp, vp, i32, u32, vp, vp, vp, vp]
     L.ria_gpu_decode_frames_host.argtypes = [vp, vp, i32, i32, u32, vp, vp]

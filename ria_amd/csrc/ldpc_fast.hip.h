@@ -599,9 +599,8 @@ __global__ __launch_bounds__(256) void fast_stage_kernel(FastDecodeArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernel Z
-// single-wave workgroups stride over the (list1 entry, factor 1..4) units: the list length is only known on
-// the device, so the grid is a fixed size and each workgroup takes units u = blockIdx, blockIdx + gridDim, ...
-// (no atomic queue: the unit -> workgroup map is static)
+// persistent single-wave workgroups pull (list1 entry, factor 1..4) units from an atomic queue (ctl->next_z): the
+// list length is only known on the device, so the grid is a fixed size; 80-iteration units and 5-iteration units mix
 template <class S>
 __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -829,6 +828,40 @@ __global__ __launch_bounds__(64) void fast_rows_kernel(FastCode c, const float* 
         int it = fast_decode(st, c, smem, factor, max_iter, lane, &ok);
         fast_pack(st, c, smem, out + static_cast<size_t>(cw) * nb, nb, lane);
         if (lane == 0) { ok_out[cw] = ok ? 1 : 0; iters_out[cw] = static_cast<uint16_t>(it); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ robust single CW
+// robustDecodeSingleCW (streaming_decoder.cpp:1028-1058): a fresh decoder at the recommended iteration count, first
+// decode at factor 0.9375, then 0.875 / 0.75 / 0.625 / 0.5 until one converges.  One wave per codeword walks the
+// factors itself (the LLRs stay in its registers).  tries = decodes made (1..5); iters = lastIterations() of the last.
+template <class S>
+__global__ __launch_bounds__(64) void fast_robust_kernel(FastCode c, const float* __restrict__ llr, int n_cw,
+                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ ok_out,
+                                                         uint16_t* __restrict__ iters_out, uint8_t* __restrict__ tries_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    FastState<S> st;
+    fast_load_tables(st, c, smem, lane);
+    const int nb = (c.k + 7) / 8;
+    for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
+        const float* l = llr + static_cast<size_t>(cw) * 648;
+#pragma unroll
+        for (int r = 0; r < S::NC; ++r) { const uint32_t j = c.col_at[lane + 64 * r]; st.li[r] = (j != 0xFFFFu) ? llr_canon(l[j]) : 0.0f; }
+#pragma unroll
+        for (int r = 0; r < S::NR; ++r) { const uint32_t i = c.check_at[lane + 64 * r]; st.lp[r] = (i != 0xFFFFu) ? llr_canon(l[c.k + i]) : kIdleRowLlr; }
+        bool ok = false;
+        int it = 0, tries = 0;
+#pragma unroll 1
+        for (int f = 0; f < kNumFactors && !ok; ++f) {
+            it = fast_decode(st, c, smem, kFactors[f], c.max_iter, lane, &ok);
+            ++tries;
+        }
+        fast_pack(st, c, smem, out + static_cast<size_t>(cw) * nb, nb, lane);
+        if (lane == 0) {
+            ok_out[cw] = ok ? 1 : 0; iters_out[cw] = static_cast<uint16_t>(it);
+            if (tries_out) tries_out[cw] = static_cast<uint8_t>(tries);
+        }
     }
 }
 

@@ -74,6 +74,11 @@ struct ria_gpu {
     unsigned int* d_l1idx = nullptr;      // [4 * ws_frames]
     unsigned int* d_l1hash = nullptr;     // [4 * ws_frames]
     int ws_frames = 0;
+    int split_parts = 0;                  // RIA_OPT_SPLIT_PARTS (0 = library default)
+    // host-buffer entry points (the single-frame IWaveform adaptor path): one device + one pinned staging block and a
+    // stream, kept for the life of the handle, grown on demand - no allocation and no device-wide sync per call
+    unsigned char* d_hstage = nullptr; unsigned char* p_hstage = nullptr; size_t hstage_bytes = 0; hipStream_t hstream = nullptr;
+    int zc_lds_opted = 0, mc_lds_opted = 0, lts_lds_opted = 0;   // dynamic-LDS opt-ins made on this handle's device
     // CRC-recovery staging (device + pinned host mirrors), sized for ws_frames
     unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr; unsigned int* d_stage2 = nullptr;
     uint8_t* d_info_c = nullptr; float* d_rows_c = nullptr; uint8_t* d_redec_ok = nullptr; uint8_t* d_redec_bytes = nullptr;
@@ -148,7 +153,8 @@ static bool shape_fits(int rate, const CoreTables& t, int* wave_lds) {
     return ok;
 }
 static hipError_t ensure_decode_ws(ria_gpu_handle h, int n_frames) {
-    if (n_frames <= h->ws_frames && h->d_ctl) return hipSuccess;
+    if (n_frames <= h->ws_frames && h->d_ctl && h->d_l1hash) return hipSuccess;
+    h->ws_frames = 0;   // nothing is valid until every allocation below has succeeded
     for (void* p_ : {(void*)h->d_entries, (void*)h->d_best, (void*)h->d_list1, (void*)h->d_res, (void*)h->d_res_bytes, (void*)h->d_win, (void*)h->d_staged, (void*)h->d_l1idx, (void*)h->d_l1hash})
         if (p_) (void)hipFree(p_);
     h->d_entries = h->d_best = h->d_list1 = nullptr; h->d_res = nullptr; h->d_res_bytes = nullptr; h->d_win = nullptr; h->d_staged = nullptr; h->d_l1idx = nullptr; h->d_l1hash = nullptr;
@@ -173,6 +179,7 @@ static void set_fast_attributes(int rate, int wb) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_robust_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(recovery_fill_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
     });
 }
@@ -378,6 +385,9 @@ void ria_gpu_destroy(ria_gpu_handle h) {
                     h->d_f_row_addr, h->d_f_col_addr, h->d_f_check_at, h->d_f_col_at, h->d_f_col_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& st_ : h->aux_stream) if (st_) (void)hipStreamDestroy(st_);
+    if (h->hstream) (void)hipStreamDestroy(h->hstream);
+    if (h->d_hstage) (void)hipFree(h->d_hstage);
+    if (h->p_hstage) (void)hipHostFree(h->p_hstage);
     for (auto& ev_ : h->aux_event) if (ev_) (void)hipEventDestroy(ev_);
     for (auto& kv : h->d_mc_mixer) if (kv.second) (void)hipFree(kv.second);
     if (h->d_mc_hilbert) (void)hipFree(h->d_mc_hilbert);
@@ -517,6 +527,12 @@ int ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out) {
     return RIA_OK;
 }
 
+int ria_gpu_set_option(ria_gpu_handle h, int option, int value) {
+    if (!h) return RIA_ERR_INVALID;
+    if (option == RIA_OPT_SPLIT_PARTS && value >= 0 && value <= kMaxParts) { h->split_parts = value; return RIA_OK; }
+    return fail(h, RIA_ERR_INVALID, "ria_gpu_set_option: unknown option %d or value %d out of range", option, value);
+}
+
 // ------------------------------------------------------------------------------------------------ decode
 int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, int max_iterations,
                               float min_sum_factor, uint8_t* out_dev, uint8_t* ok_dev, uint16_t* iters_dev,
@@ -530,6 +546,21 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
         hipLaunchKernelGGL(fast_rows_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), h->wave_lds,
                            static_cast<hipStream_t>(stream), h->fast, llr_dev, n_cw, max_iterations, min_sum_factor,
                            out_dev, ok_dev, iters_dev);
+    });
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+int ria_gpu_ldpc_decode_robust_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, uint8_t* out_dev, uint8_t* ok_dev,
+                                     uint16_t* iters_dev, uint8_t* tries_dev, void* stream) {
+    if (!h || !llr_dev || !out_dev || !ok_dev || !iters_dev || n_cw < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_ldpc_decode_robust_batch: bad argument");
+    if (n_cw == 0) return RIA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    dispatch_shape(h->cfg.code_rate, [&](auto sh) {
+        using S = decltype(sh);
+        hipLaunchKernelGGL(fast_robust_kernel<S>, dim3(std::min(n_cw, 16384)), dim3(64), h->wave_lds,
+                           static_cast<hipStream_t>(stream), h->fast, llr_dev, n_cw, out_dev, ok_dev, iters_dev, tries_dev);
     });
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
@@ -654,13 +685,18 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
     // on two internal streams: the low-occupancy phases of one half (first decodes, phase 0, finalise, CRC
     // recovery: 55-65 % VALU busy) overlap with the cascade of the other.  Results do not depend on the split.
     const char* rh = getenv("RIA_RECOVERY_HOST");
-    const bool no_split = getenv("RIA_NO_SPLIT") != nullptr || (rh && rh[0] == '1') || getenv("RIA_DEBUG_SYNC") != nullptr;
+    const bool single_stream_only = (rh && rh[0] == '1') || getenv("RIA_DEBUG_SYNC") != nullptr;   // host recovery / stage tracing own slot 0
+    int want_parts = h->split_parts;              // per handle (ria_gpu_set_option); 0: environment, else the default 2
+    if (want_parts == 0) {
+        const char* sp = getenv("RIA_SPLIT_PARTS");
+        want_parts = getenv("RIA_NO_SPLIT") ? 1 : sp ? std::max(1, std::min(kMaxParts, atoi(sp))) : 2;
+    }
+    if (single_stream_only) want_parts = 1;
     for (int done = 0; done < n_frames;) {
         int nb = n_frames - done;
         if (!llr_out_dev && nb > h->cfg.max_batch) nb = h->cfg.max_batch;
         float* llr = llr_out_dev ? llr_out_dev + static_cast<size_t>(done) * h->geo.llrs_per_frame : h->d_llr_ws;
-        static const int want_parts = getenv("RIA_SPLIT_PARTS") ? std::max(1, std::min(kMaxParts, atoi(getenv("RIA_SPLIT_PARTS")))) : 2;
-        const int n_parts = (!no_split && nb >= 4096) ? want_parts : 1;
+        const int n_parts = (nb >= 4096) ? want_parts : 1;
         {   // grow the workspaces BEFORE anything is in flight: the parts share them
             hipError_t e = ensure_decode_ws(h, nb);
             if (e == hipSuccess && (flags & RIA_DECODE_CRC_RECOVER)) e = ensure_recovery_ws(h, std::max(nb, h->cfg.max_batch), false);
@@ -701,40 +737,63 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
     return RIA_OK;
 }
 
+// staging block of the host-buffer entry points: `bytes` of device memory and as many of pinned host memory
+static int ensure_host_stage(ria_gpu_handle h, size_t bytes) {
+    if (!h->hstream) HIP_TRY(h, hipStreamCreateWithFlags(&h->hstream, hipStreamNonBlocking));
+    if (bytes <= h->hstage_bytes) return RIA_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->hstream));
+    if (h->d_hstage) (void)hipFree(h->d_hstage);
+    if (h->p_hstage) (void)hipHostFree(h->p_hstage);
+    h->d_hstage = nullptr; h->p_hstage = nullptr; h->hstage_bytes = 0;
+    bytes = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_hstage), bytes));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->p_hstage), bytes, hipHostMallocDefault));
+    h->hstage_bytes = bytes;
+    return RIA_OK;
+}
+static inline size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
+
 int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ria_frame_meta* meta_host, int n_frames,
                            uint32_t flags, uint8_t* info_out_host, ria_decode_status* decode_status_host,
                            float* llr_out_host, ria_frame_status* demod_status_host) {
-    if (!h || !samples_host || !info_out_host || !decode_status_host || n_frames <= 0)
+    const bool demod_only = (flags & RIA_RX_DEMOD_ONLY) != 0;
+    if (!h || !samples_host || n_frames <= 0 || (!demod_only && (!info_out_host || !decode_status_host)) || (demod_only && !llr_out_host))
         return fail(h, RIA_ERR_INVALID, "ria_gpu_rx_frames_host: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     const ria_gpu_geometry& g = h->geo;
-    float* d_s = nullptr; float* d_llr = nullptr; uint8_t* d_info = nullptr;
-    ria_decode_status* d_ds = nullptr; ria_frame_status* d_fs = nullptr; ria_frame_meta* d_m = nullptr;
-    size_t ns = static_cast<size_t>(n_frames) * g.frame_samples, nl = static_cast<size_t>(n_frames) * g.llrs_per_frame;
-    int rc = RIA_OK;
-    auto cleanup = [&]() { for (void* p_ : {(void*)d_s, (void*)d_llr, (void*)d_info, (void*)d_ds, (void*)d_fs, (void*)d_m}) (void)hipFree(p_); };
-#define H_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_s), ns * sizeof(float)));
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_llr), nl * sizeof(float)));
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_info), static_cast<size_t>(n_frames) * g.info_bytes_per_frame));
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_ds), n_frames * sizeof(ria_decode_status)));
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_fs), n_frames * sizeof(ria_frame_status)));
-    H_TRY(hipMemcpy(d_s, samples_host, ns * sizeof(float), hipMemcpyHostToDevice));
-    if (meta_host) {
-        H_TRY(hipMalloc(reinterpret_cast<void**>(&d_m), n_frames * sizeof(ria_frame_meta)));
-        H_TRY(hipMemcpy(d_m, meta_host, n_frames * sizeof(ria_frame_meta), hipMemcpyHostToDevice));
-    }
-    rc = ria_gpu_rx_batch(h, d_s, nullptr, d_m, n_frames, flags, d_info, d_ds, d_llr, d_fs, nullptr);
-    if (rc == RIA_OK) {
-        H_TRY(hipDeviceSynchronize());
-        H_TRY(hipMemcpy(info_out_host, d_info, static_cast<size_t>(n_frames) * g.info_bytes_per_frame, hipMemcpyDeviceToHost));
-        H_TRY(hipMemcpy(decode_status_host, d_ds, n_frames * sizeof(ria_decode_status), hipMemcpyDeviceToHost));
-        if (llr_out_host) H_TRY(hipMemcpy(llr_out_host, d_llr, nl * sizeof(float), hipMemcpyDeviceToHost));
-        if (demod_status_host) H_TRY(hipMemcpy(demod_status_host, d_fs, n_frames * sizeof(ria_frame_status), hipMemcpyDeviceToHost));
-    }
-#undef H_TRY
-    cleanup();
-    return rc;
+    const size_t n = static_cast<size_t>(n_frames);
+    // layout of the staging block (same offsets on the device and in pinned memory): inputs first, then outputs
+    const size_t o_s = 0, b_s = n * g.frame_samples * sizeof(float);
+    const size_t o_m = up256(o_s + b_s), b_m = n * sizeof(ria_frame_meta);
+    const size_t o_llr = up256(o_m + b_m), b_llr = n * g.llrs_per_frame * sizeof(float);
+    const size_t o_info = up256(o_llr + b_llr), b_info = n * g.info_bytes_per_frame;
+    const size_t o_ds = up256(o_info + b_info), b_ds = n * sizeof(ria_decode_status);
+    const size_t o_fs = up256(o_ds + b_ds), b_fs = n * sizeof(ria_frame_status);
+    const size_t total = up256(o_fs + b_fs);
+    int rc = ensure_host_stage(h, total);
+    if (rc != RIA_OK) return rc;
+    unsigned char *D = h->d_hstage, *P = h->p_hstage;
+    hipStream_t s = h->hstream;
+    std::memcpy(P + o_s, samples_host, b_s);
+    if (meta_host) std::memcpy(P + o_m, meta_host, b_m);
+    HIP_TRY(h, hipMemcpyAsync(D, P, meta_host ? o_m + b_m : b_s, hipMemcpyHostToDevice, s));   // samples (+ meta) in one copy
+    const ria_frame_meta* d_meta = meta_host ? reinterpret_cast<const ria_frame_meta*>(D + o_m) : nullptr;
+    if (demod_only)
+        rc = ria_gpu_demod_batch(h, reinterpret_cast<const float*>(D + o_s), nullptr, d_meta, n_frames, reinterpret_cast<float*>(D + o_llr),
+                                 reinterpret_cast<ria_frame_status*>(D + o_fs), s);
+    else
+        rc = ria_gpu_rx_batch(h, reinterpret_cast<const float*>(D + o_s), nullptr, d_meta, n_frames, flags, D + o_info,
+                              reinterpret_cast<ria_decode_status*>(D + o_ds), reinterpret_cast<float*>(D + o_llr),
+                              reinterpret_cast<ria_frame_status*>(D + o_fs), s);
+    if (rc != RIA_OK) return rc;
+    // outputs back in one copy (the regions wanted are contiguous in the block), one stream sync
+    const size_t out0 = (llr_out_host ? o_llr : demod_only ? o_fs : o_info);
+    HIP_TRY(h, hipMemcpyAsync(P + out0, D + out0, total - out0, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (llr_out_host) std::memcpy(llr_out_host, P + o_llr, b_llr);
+    if (!demod_only) { std::memcpy(info_out_host, P + o_info, b_info); std::memcpy(decode_status_host, P + o_ds, b_ds); }
+    if (demod_status_host) std::memcpy(demod_status_host, P + o_fs, b_fs);
+    return RIA_OK;
 }
 
 int ria_gpu_decode_frames_host(ria_gpu_handle h, const float* llr_host, int llr_stride, int n_frames, uint32_t flags,
@@ -742,23 +801,23 @@ int ria_gpu_decode_frames_host(ria_gpu_handle h, const float* llr_host, int llr_
     if (!h || !llr_host || !info_out_host || !status_host || n_frames <= 0 || llr_stride < kFrameBits)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_decode_frames_host: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    float* d_llr = nullptr; uint8_t* d_info = nullptr; ria_decode_status* d_ds = nullptr;
-    size_t nl = static_cast<size_t>(n_frames) * llr_stride, ni = static_cast<size_t>(n_frames) * h->geo.info_bytes_per_frame;
-    auto cleanup = [&]() { for (void* p_ : {(void*)d_llr, (void*)d_info, (void*)d_ds}) (void)hipFree(p_); };
-#define H_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(h, RIA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_llr), nl * sizeof(float)));
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_info), ni));
-    H_TRY(hipMalloc(reinterpret_cast<void**>(&d_ds), n_frames * sizeof(ria_decode_status)));
-    H_TRY(hipMemcpy(d_llr, llr_host, nl * sizeof(float), hipMemcpyHostToDevice));
-    int rc = ria_gpu_decode_batch(h, d_llr, llr_stride, n_frames, flags, d_info, d_ds, nullptr);
-    if (rc == RIA_OK) {
-        H_TRY(hipDeviceSynchronize());
-        H_TRY(hipMemcpy(info_out_host, d_info, ni, hipMemcpyDeviceToHost));
-        H_TRY(hipMemcpy(status_host, d_ds, n_frames * sizeof(ria_decode_status), hipMemcpyDeviceToHost));
-    }
-#undef H_TRY
-    cleanup();
-    return rc;
+    const size_t n = static_cast<size_t>(n_frames);
+    const size_t b_llr = n * llr_stride * sizeof(float), o_info = up256(b_llr), b_info = n * h->geo.info_bytes_per_frame;
+    const size_t o_ds = up256(o_info + b_info), b_ds = n * sizeof(ria_decode_status), total = up256(o_ds + b_ds);
+    int rc = ensure_host_stage(h, total);
+    if (rc != RIA_OK) return rc;
+    unsigned char *D = h->d_hstage, *P = h->p_hstage;
+    hipStream_t s = h->hstream;
+    std::memcpy(P, llr_host, b_llr);
+    HIP_TRY(h, hipMemcpyAsync(D, P, b_llr, hipMemcpyHostToDevice, s));
+    rc = ria_gpu_decode_batch(h, reinterpret_cast<const float*>(D), llr_stride, n_frames, flags, D + o_info,
+                              reinterpret_cast<ria_decode_status*>(D + o_ds), s);
+    if (rc != RIA_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(P + o_info, D + o_info, total - o_info, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::memcpy(info_out_host, P + o_info, b_info);
+    std::memcpy(status_host, P + o_ds, b_ds);
+    return RIA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ TX / channel
@@ -804,6 +863,7 @@ int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32
         return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_batch: bad argument");
     if (n_frames == 0 || frame_samples == 0) return RIA_OK;
     if (!samples_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_batch: null samples");
+    HIP_TRY(h, hipSetDevice(h->device));
     launch_channel_exact(kind, snr_db, seed, first_frame, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream));
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
@@ -837,10 +897,10 @@ int ria_gpu_sync_zc_batch(ria_gpu_handle h, const float* samples_dev, int64_t st
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.n_buffers = n_buffers; A.threshold = threshold;
     A.root_mask = root_mask & 15u; A.known_cfo = known_cfo_dev; A.ref = static_cast<const float2*>(h->d_zc_ref); A.out = out_dev;
     const int lds = buf_len * static_cast<int>(sizeof(float2)) + 4 * static_cast<int>(sizeof(ZcRootOut));
-    static std::atomic<int> lds_opted{0};
-    if (lds > lds_opted.load()) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (lds > h->zc_lds_opted) {   // the opt-in is a per-device attribute: kept per handle (= per device), not per process
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(zc_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        lds_opted.store(lds);
+        h->zc_lds_opted = lds;
     }
     hipLaunchKernelGGL(zc_detect_kernel, dim3(n_buffers), dim3(256), lds, static_cast<hipStream_t>(stream), A);
     HIP_TRY(h, hipGetLastError());
@@ -930,6 +990,7 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
     if (n_buffers == 0) return RIA_OK;
     if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || stride < buf_len)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_chirp_batch: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Two levels of chunking.  The FFT workspace (2.5 MiB per buffer) is sized for 64 buffers so that it stays
     // within the 256 MiB Infinity Cache across the eight passes of a transform pair.  The serial pieces (energy
@@ -980,11 +1041,11 @@ int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t s
     if (n_buffers == 0) return RIA_OK;
     if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || stride < buf_len)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_lts_batch: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
     if (!h->d_hilbert65) { std::vector<float> hc = build_hilbert(65); HIP_TRY(h, upload(&h->d_hilbert65, hc)); }
-    static std::atomic<int> opted{0};
-    if (!opted.load()) {
+    if (!h->lts_lds_opted) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lts_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lts_lds_bytes()));
-        opted.store(1);
+        h->lts_lds_opted = 1;
     }
     LtsArgs A{};
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.n_buffers = n_buffers; A.known_cfo = known_cfo_dev;
@@ -1000,6 +1061,7 @@ int ria_gpu_sync_cox_batch(ria_gpu_handle h, const float* samples_dev, int64_t s
     if (n_buffers == 0) return RIA_OK;
     if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || buf_len > kCoxMaxBuf || stride < buf_len)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_cox_batch: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!h->d_cox_tI) {
         const CoxTemplate t = build_cox_template(h->plan);
@@ -1053,6 +1115,7 @@ int ria_gpu_cox_preamble(ria_gpu_handle h, float* out_host, int max_n) {
 int ria_gpu_sync_host(ria_gpu_handle h, int kind, const float* samples_host, int n_samples, float threshold, float param,
                       uint32_t root_mask, void* result_out) {
     if (!h || !samples_host || !result_out || n_samples < 0 || kind < 0 || kind > 3) return RIA_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
     const size_t need = static_cast<size_t>(n_samples) * sizeof(float) + 64;
     if (need > h->sync_host_bytes) {
         if (h->d_sync_host) (void)hipFree(h->d_sync_host);
@@ -1093,6 +1156,7 @@ int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, c
     const int nc = cfg->num_carriers, num_rx = (frame_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
     const int nds = std::max(1, num_rx / cfg->spreading);
     if (llr_stride < nds * nc * cfg->bits_per_symbol) return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_demod_batch: llr_stride too small");
+    HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!h->d_mc_mixer.count(nc)) {
         void* p = nullptr;
@@ -1103,10 +1167,9 @@ int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, c
     if (!h->d_mc_hilbert) { std::vector<float> hc = build_hilbert127(); HIP_TRY(h, upload(&h->d_mc_hilbert, hc)); }
     const int lds = mcdpsk_lds_bytes(nc, frame_samples, cfg->spreading);
     if (lds > 160 * 1024) return fail(h, RIA_ERR_UNSUPPORTED, "ria_gpu_mcdpsk_demod_batch: frame too long for one workgroup's LDS");
-    static std::atomic<int> lds_opted{0};
-    if (lds > lds_opted.load()) {
+    if (lds > h->mc_lds_opted) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mcdpsk_demod_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        lds_opted.store(lds);
+        h->mc_lds_opted = lds;
     }
     // CFO-corrected samples + rotation phases live in a workspace: chunks of frames when a CFO array is given
     const int chunk = cfo_hz_dev ? std::min(n_frames, 1024) : n_frames;
@@ -1146,6 +1209,7 @@ int ria_gpu_chase_combine_batch(ria_gpu_handle h, float* acc_dev, int32_t* count
     if (!h) return RIA_ERR_INVALID;
     if (n_cw == 0) return RIA_OK;
     if (!acc_dev || !count_dev || !soft_dev || n_cw < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_chase_combine_batch: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(chase_combine_kernel, dim3(n_cw), dim3(256), 0, static_cast<hipStream_t>(stream), acc_dev, count_dev, decoded_dev,
                        soft_dev, n_cw, stored_out_dev);
     HIP_TRY(h, hipGetLastError());
@@ -1167,6 +1231,7 @@ int ria_gpu_burst_deinterleave_batch(ria_gpu_handle h, const float* physical_llr
     if (n_groups == 0 || burst_frames == 0) return RIA_OK;
     if (!physical_llr_dev || !logical_llr_out_dev || physical_llr_dev == logical_llr_out_dev || llr_stride < 2592 || burst_frames < 0 || n_groups < 0)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_burst_deinterleave_batch: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
     const int total = n_groups * burst_frames * 324;
     hipLaunchKernelGGL(burst_deinterleave_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), physical_llr_dev,
                        llr_stride, burst_frames, n_groups, logical_llr_out_dev);
@@ -1179,6 +1244,7 @@ int ria_gpu_burst_interleave_batch(ria_gpu_handle h, const uint8_t* logical_byte
     if (n_groups == 0 || burst_frames == 0) return RIA_OK;
     if (!logical_bytes_dev || !physical_bytes_out_dev || logical_bytes_dev == physical_bytes_out_dev || burst_frames < 0 || n_groups < 0)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_burst_interleave_batch: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
     const int total = n_groups * burst_frames * 324;
     hipLaunchKernelGGL(burst_interleave_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), logical_bytes_dev,
                        burst_frames, n_groups, physical_bytes_out_dev);

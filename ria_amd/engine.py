@@ -57,6 +57,10 @@ class RxEngine:
         if rc != capi.RIA_OK:
             raise capi.RiaError(f"libria_gpu status {rc}: {self.lib.ria_gpu_last_error(self.h).decode()}")
 
+    def set_split_parts(self, parts):
+        """How many parts ria_gpu_rx_batch cuts a large batch into (internal streams); 0 = library default."""
+        self._check(self.lib.ria_gpu_set_option(self.h, capi.OPT_SPLIT_PARTS, int(parts)))
+
     # ---- helpers
     def _meta(self, n, cfo_hz, abs_pos, flags):
         if cfo_hz is None and abs_pos is None and flags is None:
@@ -81,14 +85,24 @@ class RxEngine:
                               ("frame_valid", "u1"), ("needs_recovery", "u1"), ("reserved", "u1", 2)])
 
     # ---- batched calls (device tensors in, device tensors out)
-    def demod(self, samples, cfo_hz=None, abs_pos=None, flags=None, want_status=True):
-        """samples: float32 [n_frames, frame_samples] on the GPU -> (llr [n, llrs_per_frame], status)"""
-        n = samples.shape[0]
-        assert samples.dtype == torch.float32 and samples.is_contiguous() and samples.shape[1] == self.geo.frame_samples
+    def _frames_in(self, samples, offsets):
+        """(n_frames, offsets tensor or None): either [n, frame_samples] rows, or one capture + uint64 sample offsets"""
+        assert samples.dtype == torch.float32 and samples.is_contiguous()
+        if offsets is None:
+            assert samples.dim() == 2 and samples.shape[1] == self.geo.frame_samples
+            return samples.shape[0], None
+        off = np.ascontiguousarray(offsets, np.uint64)
+        assert off.size == 0 or int(off.max()) + self.geo.frame_samples <= samples.numel(), "frame runs past the capture"
+        return len(off), torch.from_numpy(off.view(np.int64)).to(self.device)
+
+    def demod(self, samples, cfo_hz=None, abs_pos=None, flags=None, want_status=True, offsets=None):
+        """samples: float32 [n_frames, frame_samples] on the GPU (or one capture + per-frame sample offsets)
+        -> (llr [n, llrs_per_frame], status)"""
+        n, off = self._frames_in(samples, offsets)
         llr = torch.empty((n, self.geo.llrs_per_frame), dtype=torch.float32, device=self.device)
         st = torch.zeros((n, 32), dtype=torch.uint8, device=self.device) if want_status else None
         meta = self._meta(n, cfo_hz, abs_pos, flags)
-        self._check(self.lib.ria_gpu_demod_batch(self.h, _ptr(samples), None, _ptr(meta), n, _ptr(llr), _ptr(st),
+        self._check(self.lib.ria_gpu_demod_batch(self.h, _ptr(samples), _ptr(off), _ptr(meta), n, _ptr(llr), _ptr(st),
                                                  _stream_ptr()))
         return llr, st
 
@@ -103,10 +117,9 @@ class RxEngine:
         return info, st
 
     def rx(self, samples, flags=capi.DECODE_FULL, cfo_hz=None, abs_pos=None, meta_flags=None, want_llr=False,
-           out=None):
+           out=None, offsets=None):
         """Fused samples -> payload bytes. Returns (info, decode_status[, llr, frame_status])."""
-        n = samples.shape[0]
-        assert samples.dtype == torch.float32 and samples.is_contiguous() and samples.shape[1] == self.geo.frame_samples
+        n, off = self._frames_in(samples, offsets)
         if out is None:
             info = torch.empty((n, self.geo.info_bytes_per_frame), dtype=torch.uint8, device=self.device)
             st = torch.zeros((n, 20), dtype=torch.uint8, device=self.device)
@@ -117,7 +130,7 @@ class RxEngine:
             llr = torch.empty((n, self.geo.llrs_per_frame), dtype=torch.float32, device=self.device)
             fst = torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
         meta = self._meta(n, cfo_hz, abs_pos, meta_flags)
-        self._check(self.lib.ria_gpu_rx_batch(self.h, _ptr(samples), None, _ptr(meta), n, flags, _ptr(info), _ptr(st),
+        self._check(self.lib.ria_gpu_rx_batch(self.h, _ptr(samples), _ptr(off), _ptr(meta), n, flags, _ptr(info), _ptr(st),
                                               _ptr(llr), _ptr(fst), _stream_ptr()))
         return (info, st, llr, fst) if want_llr else (info, st)
 
@@ -132,6 +145,19 @@ class RxEngine:
         self._check(self.lib.ria_gpu_ldpc_decode_batch(self.h, _ptr(llr_rows), n, int(max_iterations), float(factor),
                                                        _ptr(out), _ptr(ok), _ptr(it), _stream_ptr()))
         return out, ok, it
+
+    def ldpc_decode_robust(self, llr_rows):
+        """robustDecodeSingleCW over a batch: llr_rows float32 [n_cw, 648] -> (bytes, ok, iterations, tries)"""
+        n = llr_rows.shape[0]
+        assert llr_rows.dtype == torch.float32 and llr_rows.is_contiguous() and llr_rows.shape[1] == 648
+        nb = (self.geo.info_bits + 7) // 8
+        out = torch.empty((n, nb), dtype=torch.uint8, device=self.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=self.device)
+        it = torch.empty(n, dtype=torch.int16, device=self.device)
+        tries = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ria_gpu_ldpc_decode_robust_batch(self.h, _ptr(llr_rows), n, _ptr(out), _ptr(ok), _ptr(it),
+                                                              _ptr(tries), _stream_ptr()))
+        return out, ok, it, tries
 
     def ldpc_encode(self, info):
         """LDPCEncoder::encode on the host: info uint8 [n_cw, ceil(k/8)] -> coded uint8 [n_cw, 81]."""

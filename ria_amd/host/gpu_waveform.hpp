@@ -83,7 +83,9 @@ public:
     }
     void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; }                       // :73
     void setAbsoluteTrainingPosition(size_t pos) { abs_pos_ = pos; has_abs_ = true; } // :131
-    void setBurstInterleaved(bool v) { burst_marker_ = v; }   // set by detectDataSync on the host side
+    // the reference keeps TWO flags (ofdm_chirp_waveform.hpp:136-140): the one-shot that process() consumes to undo the
+    // LTS negation, and the latch StreamingDecoder reads AFTER process() (streaming_decoder.cpp:1380-1383)
+    void setBurstInterleaved(bool v) { burst_marker_ = v; burst_latched_ = v; }
     Modulation getModulation() const { return mod_; }
     CodeRate getCodeRate() const { return rate_; }
     float getFrequencyOffset() const { return cfo_hz_; }
@@ -100,12 +102,10 @@ public:
         size_t n = std::min(samples.size(), buf.size());
         std::memcpy(buf.data(), samples.data(), n * sizeof(float));
         ria_frame_meta meta{cfo_hz_, burst_marker_ ? 1u : 0u, has_abs_ ? abs_pos_ : training_start_};
-        burst_marker_ = false;  // one-shot (ofdm_chirp_waveform.cpp:423)
-        std::vector<uint8_t> info(static_cast<size_t>(g.info_bytes_per_frame));
+        burst_marker_ = false;  // one-shot (ofdm_chirp_waveform.cpp:423); burst_latched_ stays for wasBurstInterleaved()
         std::vector<float> llr(static_cast<size_t>(g.llrs_per_frame));
-        ria_decode_status ds{};
         ria_frame_status fs{};
-        int rc = ria_gpu_rx_frames_host(gpu_->get(), buf.data(), &meta, 1, 0u, info.data(), &ds, llr.data(), &fs);
+        int rc = ria_gpu_rx_frames_host(gpu_->get(), buf.data(), &meta, 1, RIA_RX_DEMOD_ONLY, nullptr, nullptr, llr.data(), &fs);
         if (rc != RIA_OK) return false;
         size_t data_syms = samples.size() / g.samples_per_symbol;
         data_syms = data_syms >= 2 ? data_syms - 2 : 0;
@@ -139,16 +139,18 @@ public:
         result.detected = false; result.correlation = 0.0f; result.cfo_hz = known_cfo_hz; result.has_training = true;
         if (ria_gpu_sync_host(gpu_->get(), 1, samples.data(), static_cast<int>(samples.size()), threshold, known_cfo_hz, 0u, &r) != RIA_OK) return false;
         result.correlation = r.correlation;
-        burst_marker_ = false;
+        burst_marker_ = false;      // both reset at the start of every detection attempt (ofdm_chirp_waveform.cpp:357-359)
+        burst_latched_ = false;
         if (r.detected) {
             result.detected = true; result.start_sample = r.start_sample;
             training_start_ = static_cast<size_t>(r.start_sample);
             synced_ = true; last_cfo_ = known_cfo_hz;
             burst_marker_ = r.burst_interleaved != 0;
+            burst_latched_ = burst_marker_;
         }
         return result.detected;
     }
-    bool wasBurstInterleaved() const { return burst_marker_; }
+    bool wasBurstInterleaved() const { return burst_latched_; }      // ofdm_chirp_waveform.hpp:101
     std::vector<float> getSoftBits() { return std::move(soft_bits_); }                // :135
     void reset() { soft_bits_.clear(); synced_ = false; has_abs_ = false; abs_pos_ = 0; }  // CFO preserved (:474-485)
     bool isSynced() const { return synced_; }
@@ -177,7 +179,7 @@ protected:
     std::vector<float> soft_bits_;
     float cfo_hz_ = 0.0f, last_cfo_ = 0.0f, last_snr_ = 0.0f, fading_index_ = 0.0f;
     size_t abs_pos_ = 0, training_start_ = 0;
-    bool has_abs_ = false, synced_ = false, burst_marker_ = false;
+    bool has_abs_ = false, synced_ = false, burst_marker_ = false, burst_latched_ = false;
 };
 
 // OFDM-COX: the same demodulator behind Schmidl-Cox acquisition (src/waveform/ofdm_cox_waveform.cpp).  process()

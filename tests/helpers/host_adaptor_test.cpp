@@ -3,7 +3,9 @@
 // -> decodeFixedFrame (streaming_decoder.cpp:723,896,1347-1363,2821).
 // usage: host_adaptor_test <mod> <rate> <frame.f32> <cfo_hz> <abs_pos> <out_prefix>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "../../ria_amd/host/gpu_waveform.hpp"
 using namespace ria_host;
@@ -26,6 +28,37 @@ int main(int argc, char** argv) {
             SyncResult r;
             bool ok = cox.detectSync(SampleSpan{x.data(), x.size()}, r, static_cast<float>(atof(argv[4])));
             printf("%d %d %.9g %.9g\n", ok ? 1 : 0, r.start_sample, r.cfo_hz, r.correlation);
+        }
+        return 0;
+    }
+    if (argc > 8 && atoi(argv[7]) == 3) {
+        // burst group in gui::StreamingDecoder's order on ONE waveform object (streaming_decoder.cpp:723-733, 896, 1347-1407,
+        // 3127-3208): detectDataSync -> setAbsoluteTrainingPosition -> per frame setFrequencyOffset / process /
+        // getSoftBits / estimatedCFO (2 Hz drift clamp); wasBurstInterleaved() is read AFTER the first process().
+        // argv: <cfo_hz> <abs_base> <out_prefix> 3 <n_frames>
+        const int n_frames = atoi(argv[8]);
+        float cfo = static_cast<float>(atof(argv[4]));
+        SyncResult r;
+        bool ok = rx.detectDataSync(SampleSpan{x.data(), std::min<size_t>(x.size(), 21000)}, r, cfo, 0.5f);
+        const int before = rx.wasBurstInterleaved() ? 1 : 0;
+        printf("%d %d %.9g %d\n", ok ? 1 : 0, r.start_sample, r.correlation, before);
+        if (!ok) return 0;
+        const size_t frame_len = static_cast<size_t>(rx.getMinSamplesForFrame());
+        size_t pos = static_cast<size_t>(r.start_sample);
+        rx.setAbsoluteTrainingPosition(static_cast<size_t>(atoll(argv[5])) + pos);
+        std::string p = argv[6];
+        for (int f = 0; f < n_frames; ++f) {
+            rx.setFrequencyOffset(cfo);
+            if (pos + frame_len > x.size()) return 4;
+            bool ready = rx.process(SampleSpan{x.data() + pos, frame_len});
+            std::vector<float> soft = rx.getSoftBits();
+            float corrected = rx.estimatedCFO();
+            printf("%d %zu %.9g %.9g %d\n", ready ? 1 : 0, soft.size(), cfo, corrected, rx.wasBurstInterleaved() ? 1 : 0);
+            float drift = corrected - cfo;
+            if (std::abs(drift) > 2.0f) corrected = cfo + std::copysign(2.0f, drift);
+            cfo = corrected;
+            FILE* o = fopen((p + "." + std::to_string(f) + ".llr").c_str(), "wb"); fwrite(soft.data(), 4, soft.size(), o); fclose(o);
+            pos += frame_len;
         }
         return 0;
     }

@@ -1,0 +1,259 @@
+"""GPU parity tests (-m gpu) of the execution modes and ABI paths around the hot path: the batch split the bench
+runs in, per-frame offsets into one capture, the burst marker / burst chain, the decode flag
+without channel de-interleave.  Everything through the C ABI, bit-exact against the oracle / the reference fixtures."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from test_gpu_parity import bits, dev, engine
+from test_oracle_golden import burst_cases, burst_cfo_feedback
+
+pytestmark = pytest.mark.gpu
+
+STATUS_FIELDS = ("cw_ok", "iterations", "attempts", "frame_valid", "needs_recovery", "reserved")
+
+
+def _bench_batch(e, n, first, seed=20261004, kind=2, snr=20.0):
+    """n frames of the bench workload (bench.py): make_frames -> tx(peak 0.8) -> the reference's own channel stream"""
+    info = e.make_frames(seed, first, n)
+    x = e.tx(info, peak=0.8)
+    e.channel_exact_(x, kind, snr, seed, first_frame=first)
+    return info, x
+
+
+def test_rx_batch_split_modes_are_bit_identical_and_match_the_reference(oracle):
+    """The bench's own execution mode: ria_gpu_rx_batch cuts a batch of >= 4096 frames into parts on internal
+    streams that share one workspace (slots / offsets).  9 000 faded bench frames through the default split (2), 3
+    and 4 parts and the single-stream path, each twice on the same handle (workspace reuse): payload bytes and every
+    ria_decode_status field identical across all runs; a 640-frame sample spread over the part boundaries equals
+    oracle.decode_fixed_frame (restatement of frame_v2.cpp:1335-1883) on the GPU's own LLRs, the LLRs equal
+    oracle.rx_process on a subsample, and - where oracle/_ref is present - the compiled reference itself."""
+    import torch
+    from ria_amd.engine import RxEngine
+    e = RxEngine("QAM16", "R1_2", max_batch=9000)
+    n, first = 9000, 25000 * 5 + 321
+    info, x = _bench_batch(e, n, first)
+    runs = {}
+    for parts in (1, 0, 3, 4, 2, 1):          # 0 = library default (2 unless the environment says otherwise)
+        e.set_split_parts(parts)
+        for rep in range(2):
+            out, st = e.rx(x)
+            torch.cuda.synchronize()
+            runs.setdefault(parts, []).append((out.cpu().numpy().copy(), e.decode_status(st).copy()))
+    base_out, base_st = runs[1][0]
+    for parts, lst in runs.items():
+        for rep, (o, s) in enumerate(lst):
+            assert np.array_equal(o, base_out), f"parts {parts} run {rep}: payload bytes differ from the single-stream run"
+            for k in STATUS_FIELDS:
+                assert np.array_equal(s[k], base_st[k]), f"parts {parts} run {rep}: status field {k}"
+    # the workload must exercise the retry machinery in every part
+    att = base_st["attempts"]
+    for lo, hi in ((0, 2250), (2250, 4500), (4500, 6750), (6750, 9000)):
+        assert (att[lo:hi] > 5).any() and (att[lo:hi] == 1).any()
+    # sample across the part boundaries of the 2-, 3- and 4-way cuts vs the oracle (and the reference)
+    e.set_split_parts(0)
+    out, st, llr, fst = e.rx(x, want_llr=True)
+    assert np.array_equal(out.cpu().numpy(), base_out)
+    llr = llr.cpu().numpy()
+    sample = np.unique(np.concatenate([np.arange(0, 64), np.arange(2218, 2282), np.arange(2968, 3032), np.arange(4468, 4532),
+                                       np.arange(5968, 6032), np.arange(6718, 6782), np.arange(8936, 9000),
+                                       np.random.default_rng(5).integers(0, n, 192)]))
+    y = x[torch.from_numpy(sample).cuda()].cpu().numpy()
+    ref = po.Ref() if po.Ref.available() else None
+    if ref is not None:
+        ref.rx_process(po.QAM16, po.R1_2, y[0])
+    bad = []
+
+    def work(lo, hi):
+        for q in range(lo, hi):
+            f = int(sample[q])
+            if q % 8 == 0:
+                lo_, _ = oracle.rx_process(po.QAM16, po.R1_2, y[q])
+                if not np.array_equal(bits(lo_), bits(llr[f])):
+                    bad.append((f, "llr"))
+            d, ok, iters, attn = oracle.decode_fixed_frame(llr[f], po.R1_2, True, 188, flags=7)
+            if not (np.array_equal(base_st["cw_ok"][f], ok) and np.array_equal(base_out[f], d)
+                    and np.array_equal(base_st["iterations"][f], iters.astype(np.uint16))
+                    and np.array_equal(base_st["attempts"][f], attn.astype(np.uint8))):
+                bad.append((f, "oracle"))
+            if ref is not None:
+                rl = ref.rx_process(po.QAM16, po.R1_2, y[q])[0]
+                rd, rok = ref.decode_fixed_frame(rl, po.R1_2, True, 188)
+                if not np.array_equal(base_st["cw_ok"][f], rok) or any(rok[c] and not np.array_equal(base_out[f][40 * c:40 * c + 40], rd[40 * c:40 * c + 40]) for c in range(4)):
+                    bad.append((f, "reference"))
+    nt = 16
+    th = [threading.Thread(target=work, args=(k * len(sample) // nt, (k + 1) * len(sample) // nt)) for k in range(nt)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not bad, bad[:8]
+    e.close()
+
+
+def test_frame_offsets_into_one_capture(oracle):
+    """frame_offsets_dev: frames at arbitrary (odd, unaligned, overlapping-free) sample offsets inside ONE capture give
+    the same LLRs, status and payload as the same frames laid out as rows; 4 200 frames so that the split path of the
+    fused call walks the offset array too."""
+    import torch
+    from ria_amd.engine import RxEngine
+    e = RxEngine("QAM16", "R1_2", max_batch=4200)
+    n = 4200
+    info, x = _bench_batch(e, n, 777, seed=99, kind=1, snr=17.0)
+    fl = e.geo.frame_samples
+    rng = np.random.default_rng(12)
+    gaps = rng.integers(0, 37, n)                      # 0..36 samples of junk between frames: most offsets not 16-byte aligned
+    offs = (np.cumsum(gaps) + np.arange(n) * fl).astype(np.uint64)
+    cap = torch.full((int(offs[-1]) + fl + 5,), 0.123, dtype=torch.float32, device="cuda")
+    idx = (torch.from_numpy(offs.astype(np.int64)).cuda()[:, None] + torch.arange(fl, device="cuda")[None, :]).reshape(-1)
+    cap[idx] = x.reshape(-1)
+    cfo = rng.uniform(-4, 4, n).astype(np.float32)
+    abs_pos = rng.integers(0, 1 << 20, n).astype(np.uint64)
+    a = e.rx(x, cfo_hz=cfo, abs_pos=abs_pos, want_llr=True)
+    b = e.rx(cap, cfo_hz=cfo, abs_pos=abs_pos, want_llr=True, offsets=offs)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+    l1, _ = e.demod(cap, cfo_hz=cfo, abs_pos=abs_pos, offsets=offs)
+    assert torch.equal(l1.view(torch.int32), a[2].view(torch.int32))
+    # and the offsets mean what the header says: a few frames against the oracle run on the capture slice itself
+    caph = cap.cpu().numpy()
+    for f in (0, 1, 2099, 2100, 4199):
+        lo, _ = oracle.rx_process(po.QAM16, po.R1_2, caph[int(offs[f]):int(offs[f]) + fl], float(cfo[f]), int(abs_pos[f]))
+        assert np.array_equal(bits(lo), bits(b[2][f].cpu().numpy())), f
+    e.close()
+
+
+@pytest.mark.parametrize("mod,rate", [("QAM16", "R1_2"), ("DQPSK", "R1_4")])
+def test_decode_without_channel_deinterleave(oracle, mod, rate):
+    """RIA_DECODE_NO_CHANNEL_DEINTERLEAVE = decodeFixedFrame(soft, rate, use_channel_interleave=false, bps)
+    (frame_v2.cpp:1347-1357): frames encoded without the per-codeword channel interleaver decode through the flag,
+    bit-exact against the oracle and the reference; the same soft bits without the flag do not."""
+    from ria_amd import capi
+    e = engine(mod, rate)
+    pm, pr = capi.MOD[mod], capi.RATE[rate]
+    g = oracle.geom(pm, pr)
+    rng = np.random.default_rng(77)
+    frames, infos = [], []
+    for f in range(24):
+        info = oracle.make_frame(rng.integers(0, 256, 4 * g.bytes_per_cw - 19, dtype=np.uint8), f, pr)
+        coded = oracle.encode_fixed_frame(info, pr, False, g.bits_per_symbol)
+        s = oracle.modulate(pm, pr, coded)
+        s = s * np.float32(0.8 / np.abs(s).max())
+        kind, snr = [(0, 14.0), (2, 18.0), (1, 12.0)][f % 3] if mod == "QAM16" else [(0, 2.0), (2, 6.0), (1, 3.0)][f % 3]
+        frames.append(oracle.channel(kind, snr, 300 + f, s))
+        infos.append(info)
+    llr, _ = e.demod(dev(np.stack(frames)))
+    out, st = e.decode(llr, flags=capi.DECODE_FULL | capi.DECODE_NO_CHANNEL_DEINTERLEAVE)
+    out, s = out.cpu().numpy(), e.decode_status(st)
+    llr_h = llr.cpu().numpy()
+    ref = po.Ref() if po.Ref.available() else None
+    n_ok = 0
+    for f in range(24):
+        d, ok, iters, att = oracle.decode_fixed_frame(llr_h[f], pr, False, g.bits_per_symbol, flags=7)
+        assert np.array_equal(s["cw_ok"][f], ok) and np.array_equal(out[f], d), f
+        assert np.array_equal(s["iterations"][f], iters.astype(np.uint16)) and np.array_equal(s["attempts"][f], att.astype(np.uint8))
+        if ref is not None:
+            rd, rok = ref.decode_fixed_frame(llr_h[f], pr, False, g.bits_per_symbol)
+            assert np.array_equal(rok, ok) and np.array_equal(rd[:len(d)], d)
+        n_ok += int(ok.all() and np.array_equal(d, infos[f]))
+    assert n_ok >= 8
+    out2, st2 = e.decode(llr, flags=capi.DECODE_FULL)
+    assert not e.decode_status(st2)["frame_valid"].any()
+
+
+def test_burst_chain_end_to_end_vs_reference_golden(oracle, golden):
+    """SURVEY.md 8f rank 3 + a9 marker, through the C ABI in StreamingDecoder's order: ria_gpu_sync_lts_batch on the
+    capture (marker from the negated first LTS) -> ria_gpu_demod_batch frame by frame at offsets inside the capture
+    (meta flag bit0 on the group's first frame, CFO fed back with the host's 2 Hz clamp) -> ria_gpu_burst_deinterleave_batch
+    -> ria_gpu_decode_batch.  Soft bits, CFOs, de-interleaved soft bits, codeword flags and bytes all identical to
+    what ONE reference OFDMChirpWaveform + BurstInterleaver + decodeFixedFrame produced (tests/golden/burst_chain.npz)."""
+    import torch
+    from ria_amd import capi
+    names = {v: k for k, v in capi.MOD.items()}, {v: k for k, v in capi.RATE.items()}
+    for i, case, x, g in burst_cases(golden, oracle):
+        mod, rate, n, lead, kind, snr, cfo0, abs_base, marker = case
+        n, abs_base = int(n), int(abs_base)
+        e = engine(names[0][int(mod)], names[1][int(rate)])
+        fl = e.geo.frame_samples
+        r = e.sync_lts(dev(x[None, :21000]), dev(np.array([cfo0], np.float32)), 0.5)[0]
+        gs = g[f"sync_{i}"]
+        assert int(r["detected"]) == 1 and int(r["start_sample"]) == int(gs[1]) and int(r["burst_interleaved"]) == int(gs[3]) == marker
+        assert np.float32(r["correlation"]).view(np.uint32) == gs[2].view(np.uint32)
+        start = int(r["start_sample"])
+        cap = dev(x)
+        cfo = np.float32(cfo0)
+        llrs = []
+        for f in range(n):
+            assert cfo == g[f"cfo_used_{i}"][f]
+            fl_flag = 1 if (f == 0 and int(r["burst_interleaved"])) else 0
+            llr, st = e.demod(cap, cfo_hz=np.array([cfo], np.float32), abs_pos=np.array([abs_base + start], np.uint64),
+                              flags=np.array([fl_flag], np.uint32), offsets=np.array([start + f * fl], np.uint64))
+            assert np.array_equal(bits(llr.cpu().numpy()[0]), bits(g[f"llr_{i}"][f])), f"case {i} frame {f}: soft bits"
+            fs = e.frame_status(st)
+            assert fs["cfo_hz"][0] == g[f"cfo_after_{i}"][f]
+            cfo = burst_cfo_feedback(cfo, fs["cfo_hz"][0])
+            llrs.append(llr)
+        phys = torch.cat(llrs).contiguous()
+        logical = e.burst_deinterleave(phys, n)
+        assert np.array_equal(bits(logical.cpu().numpy()[:, :2592]), bits(g[f"logical_{i}"])), f"case {i}: de-interleave"
+        out, st = e.decode(logical)
+        s = e.decode_status(st)
+        assert np.array_equal(s["cw_ok"], g[f"dec_ok_{i}"]), f"case {i}: {s['cw_ok']} vs {g[f'dec_ok_{i}']}"
+        assert np.array_equal(out.cpu().numpy(), g[f"dec_data_{i}"]), f"case {i}: bytes"
+        # the same group in ONE fused call per frame position is what a batched Monte-Carlo harness does: marker flag on
+        # a whole batch of first frames (here: the same frame 3 times, unmarked copy in between)
+        if marker:
+            three = cap[start:start + fl].repeat(3, 1).contiguous()
+            l3, _ = e.demod(three, cfo_hz=np.full(3, cfo0, np.float32), abs_pos=np.full(3, abs_base + start, np.uint64),
+                            flags=np.array([1, 0, 1], np.uint32))
+            l3 = l3.cpu().numpy()
+            assert np.array_equal(bits(l3[0]), bits(g[f"llr_{i}"][0])) and np.array_equal(bits(l3[2]), bits(l3[0]))
+            lo, _ = oracle.rx_process(int(mod), int(rate), x[start:start + fl], float(cfo0), abs_base + start)
+            assert np.array_equal(bits(l3[1]), bits(lo))
+
+
+def test_cpp_adaptor_burst_marker_is_latched(oracle, golden, tmp_path):
+    """The IWaveform mirror (ria_amd/host/gpu_waveform.hpp) keeps the reference's TWO marker flags
+    (ofdm_chirp_waveform.hpp:136-140): process() consumes the one-shot, wasBurstInterleaved() still reports the group
+    after process() - which is when StreamingDecoder asks (streaming_decoder.cpp:1380-1383).  Driven in the decoder's
+    order by a g++-built program over the C ABI; soft bits of every frame of the group against the reference."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_adaptor_test")
+    lib = os.path.join(root, "ria_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "helpers", "host_adaptor_test.cpp"),
+                           "-L" + lib, "-lria_gpu", "-Wl,-rpath," + lib])
+    for i, case, x, g in burst_cases(golden, oracle):
+        mod, rate, n, lead, kind, snr, cfo0, abs_base, marker = case
+        if i not in (0, 2, 4):
+            continue
+        fin = str(tmp_path / f"burst{i}.f32")
+        x.tofile(fin)
+        outp = str(tmp_path / f"b{i}")
+        lines = subprocess.check_output([exe, str(int(mod)), str(int(rate)), fin, repr(float(cfo0)), str(int(abs_base)), outp, "3",
+                                         str(int(n))]).decode().strip().split("\n")
+        head = lines[0].split()
+        gs = g[f"sync_{i}"]
+        assert int(head[0]) == 1 and int(head[1]) == int(gs[1]) and np.float32(float(head[2])) == gs[2] and int(head[3]) == marker
+        for f in range(int(n)):
+            t = lines[1 + f].split()
+            assert int(t[0]) == 1 and int(t[1]) == g[f"llr_{i}"].shape[1]
+            assert np.float32(float(t[2])) == g[f"cfo_used_{i}"][f] and np.float32(float(t[3])) == g[f"cfo_after_{i}"][f]
+            assert int(t[4]) == marker, "wasBurstInterleaved() must stay latched after process()"
+            llr = np.fromfile(f"{outp}.{f}.llr", np.float32)
+            assert np.array_equal(bits(llr), bits(g[f"llr_{i}"][f])), (i, f)
+
+
+def test_robust_single_cw_decode_vs_reference_golden(golden):
+    """ria_gpu_ldpc_decode_robust_batch = robustDecodeSingleCW (streaming_decoder.cpp:1028-1058): success, number of
+    decodes, iteration count of the last one and its bytes, against vectors recorded from the reference."""
+    g = golden("robust_ldpc")
+    for rate, rn in ((po.R1_4, "R1_4"), (po.R1_2, "R1_2"), (po.R3_4, "R3_4")):
+        e = engine("QAM16", rn)
+        r = g[f"res_{rate}"]
+        out, ok, it, tries = e.ldpc_decode_robust(dev(g[f"llr_{rate}"]))
+        assert np.array_equal(ok.cpu().numpy(), r[:, 0].astype(np.uint8)), rn
+        assert np.array_equal(tries.cpu().numpy(), r[:, 1].astype(np.uint8)), rn
+        assert np.array_equal(it.cpu().numpy(), r[:, 2].astype(np.int16)), rn
+        nb = out.shape[1]
+        assert np.array_equal(out.cpu().numpy(), r[:, 3:3 + nb].astype(np.uint8)), rn

@@ -231,3 +231,73 @@ def test_lts_sync_oracle_matches_reference_golden(oracle, golden):
     for x, cfo, r in zip(g["buffers"], g["cfo"], g["results"]):
         out = oracle.detect_data_sync(x, float(cfo), 0.5)
         assert np.array_equal(out.view(np.uint32), r.view(np.uint32)), (out, r)
+
+
+def burst_cases(golden, oracle):
+    """(case index, case tuple, rx buffer rebuilt from the recipe and checked against the recorded checksum, golden)"""
+    import gen_golden
+    g = golden("burst_chain")
+    for i, case in enumerate(gen_golden.BURST_CASES):
+        x, infos, crc = gen_golden.burst_buffer(oracle, case, i)
+        assert crc == int(g[f"crc_{i}"][0]), f"burst case {i}: rebuilt buffer differs from the one the reference saw"
+        assert np.array_equal(infos, g[f"infos_{i}"])
+        yield i, case, x, g
+
+
+def burst_cfo_feedback(cfo_used, corrected):
+    """StreamingDecoder's 2 Hz drift clamp between the frames of a burst (streaming_decoder.cpp:1397-1406,3190-3197)"""
+    cfo_used, corrected = np.float32(cfo_used), np.float32(corrected)
+    drift = np.float32(corrected - cfo_used)
+    if abs(drift) > np.float32(2.0):
+        corrected = np.float32(cfo_used + np.copysign(np.float32(2.0), drift))
+    return corrected
+
+
+def test_burst_chain_oracle_matches_reference_golden(oracle, golden):
+    """8f-3 + a9 marker: detectDataSync -> process (one-shot LTS un-negation on the first frame) -> CFO feedback from
+    frame to frame -> BurstInterleaver::deinterleave -> decodeFixedFrame, against ONE reference waveform object driven
+    in StreamingDecoder's order.  Every soft bit, CFO and decoded byte identical."""
+    for i, case, x, g in burst_cases(golden, oracle):
+        mod, rate, n, lead, kind, snr, cfo0, abs_base, marker = case
+        mod, rate, n, abs_base = int(mod), int(rate), int(n), int(abs_base)
+        sync = oracle.detect_data_sync(x[:21000], float(cfo0), 0.5)
+        gs = g[f"sync_{i}"]
+        assert np.array_equal(sync[:3].view(np.uint32), gs[:3].view(np.uint32)) and sync[3] == gs[3] == marker, (i, sync, gs)
+        start = int(sync[1])
+        fl = oracle.geom(mod, rate).frame_samples
+        cfo = np.float32(cfo0)
+        llrs = []
+        for f in range(n):
+            assert cfo == g[f"cfo_used_{i}"][f]
+            llr, aux = oracle.rx_process(mod, rate, x[start + f * fl:start + (f + 1) * fl], float(cfo), abs_base + start,
+                                         burst_marker=(f == 0 and sync[3] != 0))
+            assert bits_equal(llr, g[f"llr_{i}"][f]), f"case {i} frame {f}: soft bits"
+            assert np.float32(aux.cfo_hz) == g[f"cfo_after_{i}"][f]
+            cfo = burst_cfo_feedback(cfo, aux.cfo_hz)
+            llrs.append(llr)
+        logical = oracle.burst_deinterleave(np.stack(llrs))
+        assert bits_equal(logical, g[f"logical_{i}"])
+        bps = oracle.geom(mod, rate).bits_per_symbol
+        for f in range(n):
+            d, ok, _, _ = oracle.decode_fixed_frame(logical[f], rate, True, bps, flags=7)
+            assert np.array_equal(ok, g[f"dec_ok_{i}"][f]) and np.array_equal(d, g[f"dec_data_{i}"][f]), f"case {i} frame {f}: decode"
+
+
+def test_burst_interleaver_oracle_matches_reference_golden(oracle, golden):
+    g = golden("burst_interleaver")
+    for n in (1, 2, 3, 4, 7, 8):
+        assert np.array_equal(oracle.burst_interleave(g[f"logical_bytes_{n}"]), g[f"physical_bytes_{n}"])
+        probe = np.arange(n * 2632, dtype=np.float32).reshape(n, 2632)
+        idx = g[f"deint_index_{n}"]      # recorded on rows of 2592: physical frame * 2592 + bit
+        exp = probe[idx // 2592, idx % 2592]
+        assert np.array_equal(oracle.burst_deinterleave(probe), exp)
+
+
+def test_robust_single_cw_oracle_matches_reference_golden(oracle, golden):
+    """robustDecodeSingleCW (streaming_decoder.cpp:1028-1058): five-factor decoder diversity, recorded from the reference."""
+    g = golden("robust_ldpc")
+    for rate in (po.R1_4, po.R1_2, po.R3_4):
+        for llr, r in zip(g[f"llr_{rate}"], g[f"res_{rate}"]):
+            ok, out, it, tries = oracle.robust_decode(rate, llr)
+            assert (int(ok), tries, it) == (int(r[0]), int(r[1]), int(r[2])), (rate, r[:3], ok, tries, it)
+            assert np.array_equal(out, r[3:3 + len(out)].astype(np.uint8))
