@@ -35,6 +35,13 @@ FRAME_SETS = [
     # added later: own RNG stream (5th element) so that the sets above keep their recorded draws
     ("d8psk_r12", po.D8PSK, po.R1_2, [(0, 25.0, 0.0, 0), (2, 25.0, 0.0, 0), (1, 20.0, 1.5, 2400), (3, 24.0, 0.0, 0)], 8801),
     ("d8psk_r14", po.D8PSK, po.R1_4, [(0, 18.0, 0.0, 0), (2, 22.0, 0.0, 0)], 8802),
+    # QAM256 only exists behind the OFDM-COX waveform object (OFDMChirpWaveform::configure maps it to DQPSK,
+    # ofdm_chirp_waveform.cpp:82-89): 6th element = record through OFDMNvisWaveform (same modulator / demodulator classes)
+    ("qam256_r34", po.QAM256, po.R3_4, [(0, 38.0, 0.0, 0), (0, 31.0, 0.0, 0), (1, 36.0, 1.0, 4800), (2, 40.0, 0.0, 0)], 8803, True),
+    ("qam256_r12", po.QAM256, po.R1_2, [(0, 30.0, 0.0, 0), (1, 30.0, 0.0, 0), (0, 24.0, -2.0, 777)], 8804, True),
+    # R1/3: rate-table entry with the (324,324) default code parameters (ldpc_decoder.cpp:21-36) and 27-byte codewords
+    ("qam16_r13", po.QAM16, po.R1_3, [(0, 16.0, 0.0, 0), (2, 18.0, 0.0, 0), (1, 13.0, 0.0, 0)], 8805),
+    ("dqpsk_r13", po.DQPSK, po.R1_3, [(0, 7.0, 0.0, 0), (3, 11.0, 0.0, 0)], 8806),
 ]
 
 
@@ -312,7 +319,8 @@ def main():
             continue
         rng_frames = np.random.default_rng(entry[4]) if len(entry) > 4 else rng
         rec = {}
-        bytes_per_cw = {po.R1_4: 20, po.R1_2: 40, po.R2_3: 54, po.R3_4: 60, po.R5_6: 67}[rate]
+        nvis = len(entry) > 5 and entry[5]
+        bytes_per_cw = {po.R1_4: 20, po.R1_3: 27, po.R1_2: 40, po.R2_3: 54, po.R3_4: 60, po.R5_6: 67}[rate]
         cap = 4 * bytes_per_cw - 19
         rec["mod"], rec["rate"] = np.int32(mod), np.int32(rate)
         L = {k: [] for k in ("payload", "info", "coded", "tx", "rx", "llr", "aux", "h", "dec_data", "dec_ok",
@@ -320,10 +328,10 @@ def main():
         for f, (kind, snr, cfo, abs_pos) in enumerate(chans):
             payload = rng_frames.integers(0, 256, cap, dtype=np.uint8)
             seq = 100 + f
-            s, info, coded, bps = R.tx_frame(mod, rate, payload, seq)
+            s, info, coded, bps = R.tx_frame(mod, rate, payload, seq, nvis=nvis)
             x = s * np.float32(0.8 / np.abs(s).max())  # tools/test_waveform_simple.cpp:365-371
             y = R.channel(kind, snr, 4242 + f, x)
-            llr, aux, h, _ = R.rx_process(mod, rate, y, cfo, abs_pos)
+            llr, aux, h, _ = R.rx_process(mod, rate, y, cfo, abs_pos, nvis=nvis)
             d, ok = R.decode_fixed_frame(llr, rate, True, bps)
             L["payload"].append(payload); L["info"].append(info[:4 * bytes_per_cw]); L["coded"].append(coded)
             L["tx"].append(s if f < 2 else np.zeros(0, np.float32))

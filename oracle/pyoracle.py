@@ -289,6 +289,7 @@ class Ref:
         L.ref_channel.argtypes = [C.c_int, C.c_float, C.c_uint32, _f, C.c_int, _f]
         L.ref_rx_process.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_longlong, C.c_int, _f,
                                      C.c_int, _f, _f]
+        L.ref_rx_process_nvis.argtypes = L.ref_rx_process.argtypes
         L.ref_ldpc_decode.argtypes = [C.c_int, _f, C.c_int, C.c_int, C.c_float, _u8, C.c_int, _i]
         L.ref_detect_data_sync.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, _i, _f, _i]
         L.ref_chirp_detect.argtypes = [_f, C.c_int, C.c_float, _f]
@@ -419,13 +420,14 @@ class Ref:
         self.lib.ref_zc_detect(fp(x), len(x), threshold, root_mask, known_cfo, fp(out))
         return out
 
-    def tx_frame(self, mod, rate, payload, seq):
+    def tx_frame(self, mod, rate, payload, seq, nvis=False):
+        """nvis: through the OFDM-COX waveform object (the only one that accepts QAM256)"""
         payload = np.ascontiguousarray(payload, np.uint8)
         samples = np.zeros(80000, np.float32)
         info = np.zeros(4 * 68, np.uint8)
         coded = np.zeros(324, np.uint8)
         bps = C.c_int()
-        n = self.lib.ref_tx_frame(mod, rate, up(payload), len(payload), seq, fp(samples), len(samples),
+        n = (self.lib.ref_tx_frame_nvis if nvis else self.lib.ref_tx_frame)(mod, rate, up(payload), len(payload), seq, fp(samples), len(samples),
                                   up(info), len(info), up(coded), 324, C.byref(bps))
         assert n > 0
         return samples[:n].copy(), info, coded, bps.value
@@ -449,12 +451,12 @@ class Ref:
         self.lib.ref_channel(kind, snr_db, seed, fp(x), len(x), fp(y))
         return y
 
-    def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0, use_abs=True):
+    def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0, use_abs=True, nvis=False):
         samples = np.ascontiguousarray(samples, np.float32)
         llr = np.zeros(8 * NCAR * 64, np.float32)
         aux = np.zeros(8, np.float32)
         h = np.zeros(2 * NCAR, np.float32)
-        n = self.lib.ref_rx_process(mod, rate, fp(samples), len(samples), cfo_hz, abs_pos, int(use_abs),
+        n = (self.lib.ref_rx_process_nvis if nvis else self.lib.ref_rx_process)(mod, rate, fp(samples), len(samples), cfo_hz, abs_pos, int(use_abs),
                                     fp(llr), len(llr), fp(aux), fp(h))
         return llr[:abs(n)].copy(), aux, h, n > 0
 

@@ -474,6 +474,66 @@ int ref_burst_deinterleave(int n_frames, const float* physical, float* logical) 
     return 0;
 }
 
+// ---------------------------------------------------------------- the same two calls on the OFDM-COX waveform object
+// OFDMChirpWaveform::configure maps QAM256 (and QAM8) to DQPSK (ofdm_chirp_waveform.cpp:82-89); OFDMNvisWaveform::configure
+// takes any modulation (ofdm_cox_waveform.cpp:71-91) and its process() drives the same OFDMDemodulator::processPresynced
+// (:164-214).  TX = the waveform's own OFDMModulator: 2 training symbols + modulate, as generateDataPreamble does.
+int ref_tx_frame_nvis(int mod, int rate, const uint8_t* payload, int payload_len, int seq, float* samples_out, int max_samples,
+                      uint8_t* frame_info_out, int max_info, uint8_t* coded_out, int max_coded, int* bits_per_symbol_out) {
+    ref_quiet();
+    OFDMNvisWaveform tx(named_config(mod, rate));
+    tx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    CodeRate cr = static_cast<CodeRate>(rate);
+    Bytes pl(payload, payload + payload_len);
+    Bytes fd = protocol::v2::makeFixedDataFrame("TEST", "RX", static_cast<uint16_t>(seq), pl, cr).serialize();
+    int pilots = (tx.config_.num_carriers + tx.config_.pilot_spacing - 1) / tx.config_.pilot_spacing;
+    size_t bps = (tx.config_.num_carriers - pilots) * getBitsPerSymbol(static_cast<Modulation>(mod));
+    if (bits_per_symbol_out) *bits_per_symbol_out = static_cast<int>(bps);
+    Bytes enc = protocol::v2::encodeFixedFrame(fd, cr, true, bps);
+    Samples pre = tx.modulator_->generateTrainingSymbols(2);
+    Samples dat = tx.modulate(enc);
+    size_t info_bytes = 4 * protocol::v2::getBytesPerCodeword(cr);
+    if (frame_info_out) { Bytes padded = fd; padded.resize(info_bytes, 0); std::memcpy(frame_info_out, padded.data(), std::min<size_t>(info_bytes, max_info)); }
+    if (coded_out) std::memcpy(coded_out, enc.data(), std::min<size_t>(enc.size(), max_coded));
+    int n = static_cast<int>(pre.size() + dat.size());
+    if (n > max_samples) return -n;
+    std::memcpy(samples_out, pre.data(), pre.size() * sizeof(float));
+    std::memcpy(samples_out + pre.size(), dat.data(), dat.size() * sizeof(float));
+    return n;
+}
+int ref_rx_process_nvis(int mod, int rate, const float* samples, int n, float cfo_hz, long long abs_pos, int use_abs,
+                        float* llr_out, int max_llr, float* aux_out, float* h_out) {
+    ref_quiet();
+    OFDMNvisWaveform rx(named_config(mod, rate));
+    rx.configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    rx.reset();
+    if (use_abs) rx.setAbsoluteTrainingPosition(static_cast<size_t>(abs_pos));
+    rx.setFrequencyOffset(cfo_hz);
+    bool ok = rx.process(SampleSpan(samples, n));
+    std::vector<float> soft = rx.getSoftBits();
+    int m = static_cast<int>(soft.size());
+    if (llr_out) std::memcpy(llr_out, soft.data(), std::min(m, max_llr) * sizeof(float));
+    auto* impl = rx.demodulator_->impl_.get();
+    if (aux_out) {
+        aux_out[0] = rx.demodulator_->getEstimatedSNR();
+        aux_out[1] = rx.demodulator_->getFrequencyOffset();
+        aux_out[2] = impl->last_fading_index;
+        aux_out[3] = impl->noise_variance;
+        aux_out[4] = impl->lts_phase_slope;
+        aux_out[5] = impl->estimated_snr_linear;
+        aux_out[6] = impl->freq_correction_phase;
+        aux_out[7] = static_cast<float>(impl->snr_symbol_count);
+    }
+    if (h_out) {
+        for (size_t i = 0; i < impl->all_carrier_fft_indices.size(); ++i) {
+            Complex h = impl->channel_estimate[impl->all_carrier_fft_indices[i]];
+            h_out[2 * i] = h.real();
+            h_out[2 * i + 1] = h.imag();
+        }
+    }
+    return ok ? m : -m;
+}
+
 // ---------------------------------------------------------------- burst chain
 // TX of one burst-interleaved group as StreamingEncoder::encodeBurstLight builds it (streaming_encoder.cpp:302-389):
 // every frame LDPC-encoded + frame/channel-interleaved (encodeFixedFrame), the group byte-interleaved

@@ -70,12 +70,19 @@ private:
 // One configured OFDM-CHIRP waveform object whose process() runs on the GPU (n_frames = 1).
 class GpuOfdmChirpWaveform /* : public ultra::IWaveform on the reference side */ {
 public:
-    explicit GpuOfdmChirpWaveform(Modulation mod = Modulation::QAM16, CodeRate rate = CodeRate::R1_2, int device = 0)
-        : device_(device) { configure(mod, rate); }
+    explicit GpuOfdmChirpWaveform(Modulation mod = Modulation::QAM16, CodeRate rate = CodeRate::R1_2, int device = 0, bool any_modulation = false)
+        : device_(device) { if (any_modulation) configureImpl(mod, rate); else configure(mod, rate); }
 
     std::string getName() const { return "OFDM-CHIRP (MI355X)"; }
     // configure() rebuilds the internals like the reference does (ofdm_chirp_waveform.cpp:81-107)
-    void configure(Modulation mod, CodeRate rate) {
+    void configure(Modulation mod, CodeRate rate) { configureImpl(allowedOnChirp(mod) ? mod : Modulation::DQPSK, rate); }
+    // OFDMChirpWaveform::configure accepts DBPSK/DQPSK/D8PSK/QPSK/BPSK/QAM16/QAM32/QAM64 and maps everything else
+    // (QAM8, QAM256) to DQPSK with a warning (ofdm_chirp_waveform.cpp:82-89); OFDM-COX takes any modulation
+    static bool allowedOnChirp(Modulation m) {
+        return m == Modulation::DBPSK || m == Modulation::DQPSK || m == Modulation::D8PSK || m == Modulation::QPSK ||
+               m == Modulation::BPSK || m == Modulation::QAM16 || m == Modulation::QAM32 || m == Modulation::QAM64;
+    }
+    void configureImpl(Modulation mod, CodeRate rate) {
         mod_ = mod; rate_ = rate;
         gpu_ = std::make_unique<GpuHandle>(mod, rate, device_);
         soft_bits_.clear();
@@ -189,9 +196,9 @@ protected:
 class GpuOfdmCoxWaveform : public GpuOfdmChirpWaveform {
 public:
     explicit GpuOfdmCoxWaveform(Modulation mod = Modulation::QAM16, CodeRate rate = CodeRate::R1_2, int device = 0)
-        : GpuOfdmChirpWaveform(mod, rate, device) {}
+        : GpuOfdmChirpWaveform(mod, rate, device, true) {}
     std::string getName() const { return "OFDM-COX (MI355X)"; }
-    void configure(Modulation mod, CodeRate rate) { GpuOfdmChirpWaveform::configure(mod, rate); noise_floor_ = 0.0f; }
+    void configure(Modulation mod, CodeRate rate) { configureImpl(mod, rate); noise_floor_ = 0.0f; }   // ofdm_cox_waveform.cpp:71-91
     std::vector<float> generatePreamble() {                                          // ofdm_cox_waveform.cpp:107-112
         std::vector<float> p(8 * static_cast<size_t>(gpu_->geo().samples_per_symbol));
         int n = ria_gpu_cox_preamble(gpu_->get(), p.data(), static_cast<int>(p.size()));

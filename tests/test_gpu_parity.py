@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 
 FRAME_SETS = {"qam16_r12": ("QAM16", "R1_2"), "dqpsk_r12": ("DQPSK", "R1_2"), "qam64_r34": ("QAM64", "R3_4"),
               "qam32_r34": ("QAM32", "R3_4"), "qpsk_r12": ("QPSK", "R1_2"), "dqpsk_r14": ("DQPSK", "R1_4"),
-              "qam16_r34": ("QAM16", "R3_4"), "d8psk_r12": ("D8PSK", "R1_2"), "d8psk_r14": ("D8PSK", "R1_4")}
+              "qam16_r34": ("QAM16", "R3_4"), "d8psk_r12": ("D8PSK", "R1_2"), "d8psk_r14": ("D8PSK", "R1_4"),
+              # QAM256 recorded through the OFDM-COX waveform object (OFDM-CHIRP's configure() maps it to DQPSK); R1/3
+              "qam256_r34": ("QAM256", "R3_4"), "qam256_r12": ("QAM256", "R1_2"), "qam16_r13": ("QAM16", "R1_3"),
+              "dqpsk_r13": ("DQPSK", "R1_3")}
 _engines = {}
 
 
@@ -203,7 +206,8 @@ def test_crc_recovery_device_vs_host_vs_oracle(oracle, monkeypatch, mod, rate, s
 
 
 @pytest.mark.parametrize("mod,rate", [("QAM16", "R1_2"), ("DQPSK", "R1_2"), ("QAM64", "R3_4"), ("QPSK", "R1_2"),
-                                      ("QAM32", "R3_4"), ("BPSK", "R1_2"), ("DBPSK", "R1_4"), ("D8PSK", "R1_2")])
+                                      ("QAM32", "R3_4"), ("BPSK", "R1_2"), ("DBPSK", "R1_4"), ("D8PSK", "R1_2"),
+                                      ("QAM256", "R3_4"), ("QAM16", "R1_3")])
 def test_tx_samples_bit_exact_vs_oracle(oracle, mod, rate):
     from ria_amd import capi
     e = engine(mod, rate)

@@ -7,7 +7,8 @@ import pytest
 
 import pyoracle as po
 
-FRAME_SETS = ["qam16_r12", "dqpsk_r12", "qam64_r34", "qam32_r34", "qpsk_r12", "dqpsk_r14", "qam16_r34", "d8psk_r12", "d8psk_r14"]
+FRAME_SETS = ["qam16_r12", "dqpsk_r12", "qam64_r34", "qam32_r34", "qpsk_r12", "dqpsk_r14", "qam16_r34", "d8psk_r12", "d8psk_r14",
+              "qam256_r34", "qam256_r12", "qam16_r13", "dqpsk_r13"]
 
 
 def bits_equal(a, b):
