@@ -29,6 +29,41 @@ ALGO_BYTES_FRAME = 18432 * 4 + 160          # samples in + pay
 ALGO_BYTES_DEMOD = 18432 * 4 + 2632 * 4     # demod kernel alone: samples in + LLRs out
 ALGO_BYTES_DECODE = 2592 * 4 + 160          # decode kernel alone: LLRs in + payload out
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_INSTS = 256 * 4 * 2.4e9 / 4        # wave64 VALU instructions/s: 1024 SIMD16 units x 2.4 GHz, 4 cycles per wave-instruction
+DECODE_STAGE = ("fast_primary_kernel", "fast_mark_kernel", "fast_stage_kernel", "fast_phase0_kernel", "fast_chain_kernel",
+                "fast_cascade_kernel", "fast_finalize_kernel", "frame_validate_kernel")
+
+
+def host_cores():
+    """CPUs this process may use: the affinity mask, capped by the cgroup CPU quota where one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def matching_profile(suffix, src_hash):
+    """newest profiles/*<suffix> whose recorded kernel-source hash is the current one, or (None, reason)"""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=os.path.getmtime, reverse=True)
+    seen = 0
+    for p in cands:
+        try:
+            d = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        meta = d.get("_meta")
+        if not meta:
+            continue
+        seen += 1
+        if meta.get("source_sha256") == src_hash:
+            return d, os.path.relpath(p, ROOT)
+    return None, (f"no profiles/*{suffix} was measured on the current kernel sources (sha256 {src_hash[:12]}; "
+                  f"{seen} tagged profile(s) are of other builds)")
 
 
 def cpu_baseline(frames_host, seconds_budget=20.0):
@@ -37,7 +72,7 @@ def cpu_baseline(frames_host, seconds_budget=20.0):
     restatement (kind 'port').  The oracle is used here only as the timed baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    cores = host_cores()   # all host cores this process may use (SURVEY.md 8d), count stated in the result
     kind = "port"
     ref = None
     if po.Ref.available():
@@ -86,7 +121,10 @@ def cpu_baseline(frames_host, seconds_budget=20.0):
                       f"{dt:.1f} s wall on {cores} threads, full decodeFixedFrame incl. retry cascade"}
 
 
-def main():
+def main(argv=None, engine_factory=None):
+    """engine_factory: tests/test_bench_gloo.py passes a CPU stand-in for RxEngine to run this function's N > 1 control
+    flow (seed broadcast, global frame indices, barrier, max-over-ranks time, counter all-reduce, rank-0 JSON line) with
+    world_size 2 on gloo; None = the real engine on this rank's GPU."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -96,7 +134,13 @@ def main():
     ap.add_argument("--snr", type=float, default=20.0)
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--steps-only", action="store_true",
+                    help="profiling passes: only the warm-up + timed steps run on the GPU (no per-kernel timing section, no CPU leg), "
+                         "so that a counter summed over the run divides by warmup + steps")
+    args = ap.parse_args(argv)
+    stub = engine_factory is not None
+    if stub:
+        args.steps_only = True
 
     import torch
     import torch.distributed as dist
@@ -111,16 +155,20 @@ def main():
     rehearse = os.environ.get("RIA_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
-    if world > 1:
+    own_group = False
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if rehearse:
+        own_group = True
+        if stub or rehearse:
             dist.init_process_group("gloo")
         else:
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    cdev = torch.device("cpu") if rehearse else dev      # where the few-byte collectives live
+    dev = torch.device("cpu") if stub else torch.device("cuda", local)
+    if not stub:
+        torch.cuda.set_device(dev)
+    device_sync = (lambda: None) if stub else torch.cuda.synchronize
+    cdev = torch.device("cpu") if (rehearse or stub) else dev      # where the few-byte collectives live
 
     # seed broadcast (the only data-path-adjacent collective: tens of bytes over xGMI)
     seed_t = torch.tensor([args.seed], dtype=torch.int64, device=cdev)
@@ -129,7 +177,7 @@ def main():
     seed = int(seed_t.item())
 
     B = args.batch
-    e = RxEngine("QAM16", "R1_2", device=local, max_batch=B)
+    e = engine_factory(B) if stub else RxEngine("QAM16", "R1_2", device=local, max_batch=B)
     n_sets = args.steps + args.warmup
     # every step gets its own input batch up to 16 resident batches (29 GB at the default size); longer runs cycle
     # through them - the work per step is the same, nothing is cached between steps
@@ -142,15 +190,15 @@ def main():
         e.channel_exact_(x, args.channel, args.snr, seed, first_frame=first)   # the reference's own mt19937 stream: seed + frame
         batches.append(x)
         infos.append(info)
-    torch.cuda.synchronize()
+    device_sync()
     out = (torch.empty((B, e.geo.info_bytes_per_frame), dtype=torch.uint8, device=dev),
            torch.zeros((B, 20), dtype=torch.uint8, device=dev))
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for s in range(args.warmup):
         e.rx(batches[s % n_pool], out=out)
@@ -175,48 +223,69 @@ def main():
 
     # live per-kernel durations with HIP events on the stream the kernels are launched on
     # (torch's current stream is the stream handed to the C ABI).
-    x = batches[-1]
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    llr, _ = e.demod(x, want_status=False)
-    torch.cuda.synchronize()
-    reps = 3
-    t_demod = t_decode = 0.0
-    flags_nohost = capi.DECODE_PHASE0 | capi.DECODE_PERTURB
-    for rep in range(reps + 1):          # the first pass is a warm-up (allocator, clocks) and is not counted
-        if rep == 1:
-            t_demod = t_decode = 0.0
-        ev[0].record()
+    t_demod = t_decode = None
+    if not args.steps_only:
+        x = batches[-1]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         llr, _ = e.demod(x, want_status=False)
-        ev[1].record()
-        ev[2].record()
-        e.decode(llr, flags=flags_nohost)
-        ev[3].record()
         torch.cuda.synchronize()
-        t_demod += ev[0].elapsed_time(ev[1]) / reps
-        t_decode += ev[2].elapsed_time(ev[3]) / reps
-    if t_decode >= t_demod:
-        dom, dur_ms, algo = "decode stage (fast_primary/mark/stage/phase0/chain/cascade/finalize + frame_validate kernels)", t_decode, ALGO_BYTES_DECODE * B
-    else:
-        dom, dur_ms, algo = "demod_frames_kernel", t_demod, ALGO_BYTES_DEMOD * B
-    achieved = algo / (dur_ms * 1e-3) / 1e9
-    # HBM traffic and VALU/LDS utilisation cannot be measured from inside the process: they come from the
-    # rocprofv3 --pmc passes of THIS command committed under profiles/ (per 25 000-frame launch, FETCH_SIZE
-    # doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read; Infinity-Cache hits included).
-    traffic, pmc_note, valu = None, None, None
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01o_hbm_traffic_pmc.json")))
-        if B == 25000:
-            stage = ["fast_primary_kernel", "fast_mark_kernel", "fast_stage_kernel", "fast_phase0_kernel", "fast_chain_kernel", "fast_cascade_kernel",
-                     "fast_finalize_kernel", "frame_validate_kernel"] if t_decode >= t_demod else ["demod_frames_kernel"]
-            traffic = int(sum(v["hbm_bytes_per_launch"] for k, v in tr.items() if any(n in k for n in stage)))
-            pmc_note = "profiles/r01o_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r01o_sq_utilisation_pmc.json")))
-        c = sq.get("ria::fast_cascade_kernel<ria::ShapeR12>")
-        if c:
-            valu = {"kernel": "fast_cascade_kernel", "valu_busy_frac": c["valu_busy_frac"], "lds_busy_frac": c["lds_busy_frac"],
-                    "source": "profiles/r01o_sq_utilisation_pmc.json"}
-    except (OSError, ValueError, KeyError):
-        pass
+        reps = 3
+        flags_nohost = capi.DECODE_PHASE0 | capi.DECODE_PERTURB
+        for rep in range(reps + 1):          # the first pass is a warm-up (allocator, clocks) and is not counted
+            if rep <= 1:
+                t_demod = t_decode = 0.0
+            ev[0].record()
+            llr, _ = e.demod(x, want_status=False)
+            ev[1].record()
+            ev[2].record()
+            e.decode(llr, flags=flags_nohost)
+            ev[3].record()
+            torch.cuda.synchronize()
+            t_demod += ev[0].elapsed_time(ev[1]) / reps
+            t_decode += ev[2].elapsed_time(ev[3]) / reps
+    roof = None
+    if t_decode is not None:
+        if t_decode >= t_demod:
+            dom, dur_ms, algo = "decode stage (fast_primary/mark/stage/phase0/chain/cascade/finalize + frame_validate kernels)", t_decode, ALGO_BYTES_DECODE * B
+            stage = DECODE_STAGE
+        else:
+            dom, dur_ms, algo = "demod_frames_kernel", t_demod, ALGO_BYTES_DEMOD * B
+            stage = ("demod_frames_kernel",)
+        achieved = algo / (dur_ms * 1e-3) / 1e9
+        # HBM traffic and instruction counts cannot be measured from inside the process: they come from the rocprofv3
+        # --pmc passes of THIS command (tools/measure_round.sh) summarised under profiles/ - and only from a summary
+        # whose recorded kernel-source hash equals the sources this run was built from; otherwise null with the reason.
+        from ria_amd.srchash import csrc_sha256
+        src = csrc_sha256()
+        traffic = traffic_src = valu = valu_issue = None
+        tr, tr_path = matching_profile("_hbm_traffic_pmc.json", src)
+        if tr is not None and tr["_meta"].get("frames_per_launch") == B:
+            traffic = int(sum(v["hbm_bytes_per_launch"] for k, v in tr.items() if k != "_meta" and any(n in k for n in stage)))
+            traffic_src = tr_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one launch = one whole step; FETCH_SIZE x2 for gfx950)"
+        else:
+            traffic_src = tr_path if tr is None else f"{tr_path} was measured at {tr['_meta'].get('frames_per_launch')} frames per launch, this run at {B}"
+        sq, sq_path = matching_profile("_sq_utilisation_pmc.json", src)
+        if sq is not None and sq["_meta"].get("frames_per_step") == B:
+            m = sq["_meta"]
+            c = next((v for k, v in sq.items() if "fast_cascade_kernel" in k), None)
+            if c:
+                valu = {"kernel": "fast_cascade_kernel", "valu_busy_frac": c["valu_busy_frac"], "lds_busy_frac": c["lds_busy_frac"],
+                        "lds_bank_conflict_share": c["lds_bank_conflict_share"], "source": sq_path}
+            dec_insts = sum(v["valu_insts"] * v["launches"] for k, v in sq.items() if k != "_meta" and any(n in k for n in DECODE_STAGE)) / m["steps_counted"]
+            all_insts = sum(v["valu_insts"] * v["launches"] for k, v in sq.items() if k != "_meta" and any(n in k for n in DECODE_STAGE + ("demod_frames_kernel", "recovery_"))) / m["steps_counted"]
+            valu_issue = {"peak_insts_per_s": VALU_PEAK_INSTS, "unit": "wave64 VALU instructions (SQ_INSTS_VALU)",
+                          "decode_stage": {"insts_per_step": int(dec_insts), "ms": round(t_decode, 3),
+                                           "frac": round(dec_insts / (t_decode * 1e-3) / VALU_PEAK_INSTS, 4)},
+                          "fused_step": {"insts_per_step": int(all_insts), "ms": round(elapsed / args.steps * 1e3, 3),
+                                         "frac": round(all_insts / (elapsed / args.steps) / VALU_PEAK_INSTS, 4)},
+                          "source": sq_path + " (instruction counts; the times are this run's)"}
+        else:
+            valu = {"source": sq_path if sq is None else f"{sq_path}: other batch size"}
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
+                "limiter": "FP32 VALU issue + LDS, not HBM (SURVEY.md 8d): see valu_issue", "valu": valu, "valu_issue": valu_issue,
+                "kernel_source_sha256": src}
 
     if rank == 0:
         res = {
@@ -240,23 +309,17 @@ def main():
                 "frames_decoded_last_step": int(cnt[1].item()), "frames_bytes_equal_tx_last_step": int(cnt[2].item()),
                 "fused_path_GBps": round(total_frames / elapsed * ALGO_BYTES_FRAME / 1e9, 2),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": dom,
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "traffic_source": pmc_note,
-                "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
-                "limiter": "FP32 VALU issue + LDS, not HBM (SURVEY.md 8d): see valu", "valu": valu,
-            },
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.steps_only:
             n_cpu = 4096
             res["cpu_baseline"] = cpu_baseline(batches[-1][:n_cpu].cpu().numpy())
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if own_group:
         dist.destroy_process_group()
+    return res if rank == 0 else None
 
 
 if __name__ == "__main__":

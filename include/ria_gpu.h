@@ -354,6 +354,12 @@ int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, ui
 int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32_t seed, uint64_t first_frame,
                                 float* samples_dev, int64_t stride, int frame_samples, int n_frames, void* stream);
 
+/* The same channel with one mt19937 seed PER FRAME (seeds_dev[f]): Monte-Carlo drivers derive the seed of a trial from
+ * (base seed, sweep point, transmission number, global trial index), so that a trial's noise does not depend on how
+ * trials are batched, compacted or spread over GPUs.  Frame f = sim::WattersonChannel(cfg, seeds_dev[f]), bit-identical. */
+int ria_gpu_channel_exact_seeded_batch(ria_gpu_handle h, int kind, float snr_db, const uint32_t* seeds_dev, float* samples_dev,
+                                       int64_t stride, int frame_samples, int n_frames, void* stream);
+
 /* ---- burst interleaver (fec::BurstInterleaver, src/fec/burst_interleaver.cpp:8-78) -----------------
  * A burst of N physical frames carries N logical frames byte-interleaved: physical[(N*b+f)/324][(N*b+f)%324] =
  * logical[f][b].  deinterleave works on the soft bits (8 per byte) of n_groups bursts of N frames each:

@@ -289,6 +289,39 @@ def robust_fixture(R):
     return rec
 
 
+# (carriers, bits per symbol, spreading, channel kind, snr dB): the MC-DPSK rungs of the ladder (waveform_selection.hpp:112-222)
+# at two marginal SNRs each (sigma from the rms of the non-zero samples, as sim::WattersonChannel defines it), one faded
+HARQ_CASES = [(10, 1, 4, 0, -22.0), (10, 1, 4, 0, -20.0), (10, 1, 2, 0, -19.0), (10, 1, 2, 0, -17.0), (10, 1, 1, 0, -16.0),
+              (10, 1, 1, 0, -14.0), (10, 2, 1, 0, -12.0), (10, 2, 1, 0, -10.0), (10, 1, 1, 1, -9.0), (10, 2, 1, 2, -3.0)]
+HARQ_TRIALS, HARQ_SEED = 192, 424242
+
+
+def harq_inputs(case_index, n=HARQ_TRIALS):
+    """(info [n, 21], seeds [n, 4]) of a HARQ case: the sweep's own per-trial recipe (ria_amd/sweep.py)"""
+    sys.path.insert(0, os.path.dirname(po.HERE))
+    from ria_amd import sweep
+    trials = np.arange(n)
+    info = sweep.trial_payloads(HARQ_SEED, case_index, trials, 16)
+    seeds = np.stack([sweep.trial_seed32(HARQ_SEED, case_index, t, trials) for t in range(4)], axis=1)
+    return info, seeds
+
+
+def harq_fixture(R):
+    """BASELINE config 5, MC-DPSK rungs: per trial the reference's modulator -> WattersonChannel(seed) -> demodulator ->
+    robustDecodeSingleCW / ChaseCache / robustDecodeSingleCW of the sum, up to 4 transmissions (ref_shim.cpp ref_harq_trials).
+    Recorded: transmissions to success, checksum of every reception's soft bits and of every cache sum, decoder tries,
+    decoded bytes, the demodulator's fading index."""
+    rec = {"cases": np.array(HARQ_CASES, np.float64), "trials": np.int32(HARQ_TRIALS), "seed": np.int64(HARQ_SEED)}
+    for i, (nc, bps, sp, kind, snr) in enumerate(HARQ_CASES):
+        info, seeds = harq_inputs(i)
+        r = R.harq_trials(nc, bps, sp, kind, snr, info, seeds)
+        for k in ("tx_to_success", "llr_crc", "acc_crc", "tries", "decoded", "fading"):
+            rec[f"{k}_{i}"] = r[k]
+        good = (r["tx_to_success"] > 0) & (r["decoded"] == info[:, :20]).all(axis=1)
+        print("harq case", i, HARQ_CASES[i], "tx-to-success histogram", np.bincount(r["tx_to_success"], minlength=5), "correct", int(good.sum()))
+    return rec
+
+
 def chirp_fixture(R):
     chirp = R.chirp_generate()
     rec = {"preamble_crc": np.array([__import__("zlib").crc32(chirp.tobytes())], np.uint32), "cases": np.array(CHIRP_CASES, np.float32)}
@@ -346,6 +379,9 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"frames_{name}.npz"), **rec)
         print(name, "frames", len(chans), "decoded", [int(o.all()) for o in L["dec_ok"]])
 
+    if only == "harq":
+        np.savez_compressed(os.path.join(OUT, "harq_trials.npz"), **harq_fixture(R))
+        return 0
     if only == "robust":
         np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
         return 0
@@ -422,6 +458,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "burst_chain.npz"), **burst_fixture(R, O))
     np.savez_compressed(os.path.join(OUT, "burst_interleaver.npz"), **burst_interleaver_fixture(R))
     np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "harq_trials.npz"), **harq_fixture(R))
     print("done ->", OUT)
     return 0
 

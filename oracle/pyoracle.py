@@ -307,6 +307,8 @@ class Ref:
         L.ref_burst_tx.argtypes = [C.c_int, C.c_int, _u8, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, _u8, _u8]
         L.ref_burst_rx.argtypes = [C.c_int, C.c_int, _f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _i64, _f, _f, C.c_int,
                                    _f, _f, _f, _u8, _u8]
+        _u32 = C.POINTER(C.c_uint32)
+        L.ref_harq_trials.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _u8, _u32, C.c_int, C.c_int, _i, _u32, _u32, _i, _u8, _f]
         L.ref_burst_interleave.argtypes = [C.c_int, _u8, _u8]
         L.ref_burst_deinterleave.argtypes = [C.c_int, _f, _f]
         L.ref_quiet()
@@ -349,6 +351,19 @@ class Ref:
         out = np.zeros_like(physical)
         self.lib.ref_burst_deinterleave(physical.shape[0], fp(physical), fp(out))
         return out
+
+    def harq_trials(self, nc, bps, spreading, kind, snr_db, info21, seeds):
+        """MC-DPSK data codeword + HARQ chase combining through the reference's modulator / channel / demodulator /
+        ChaseCache / LDPCDecoder (oracle/ref_shim.cpp ref_harq_trials).  info21 uint8 [n, 21], seeds uint32 [n, max_tx]."""
+        info21 = np.ascontiguousarray(info21, np.uint8)
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        n, max_tx = seeds.shape
+        tts = np.zeros(n, np.int32); lc = np.zeros((n, max_tx), np.uint32); ac = np.zeros((n, max_tx), np.uint32)
+        tries = np.zeros((n, max_tx, 2), np.int32); dec = np.zeros((n, 20), np.uint8); fad = np.zeros((n, max_tx), np.float32)
+        rc = self.lib.ref_harq_trials(nc, bps, spreading, kind, snr_db, up(info21), seeds.ctypes.data_as(C.POINTER(C.c_uint32)), n, max_tx,
+                                      ip(tts), lc.ctypes.data_as(C.POINTER(C.c_uint32)), ac.ctypes.data_as(C.POINTER(C.c_uint32)), ip(tries), up(dec), fp(fad))
+        assert rc == 0, rc
+        return {"tx_to_success": tts, "llr_crc": lc, "acc_crc": ac, "tries": tries, "decoded": dec, "fading": fad}
 
     def burst_tx(self, mod, rate, infos, negate_first_lts=True):
         """One burst group as StreamingEncoder::encodeBurstLight builds it: infos uint8 [N, info_bytes] ->

@@ -39,6 +39,7 @@
 #include "ultra/types.hpp"
 #include "fec/frame_interleaver.hpp"
 #include "fec/burst_interleaver.hpp"
+#include "fec/chase_cache.hpp"
 #include "fec/ldpc_codec.hpp"
 #include "protocol/frame_v2.hpp"
 #include "sim/hf_channel.hpp"
@@ -532,6 +533,96 @@ int ref_rx_process_nvis(int mod, int rate, const float* samples, int n, float cf
         }
     }
     return ok ? m : -m;
+}
+
+// ---------------------------------------------------------------- HARQ trial chain of the MC-DPSK rungs (BASELINE config 5)
+static uint32_t crc32_bytes(const void* p, size_t n) {   // zlib's CRC-32 (so that numpy-side zlib.crc32 checks it)
+    static uint32_t tab[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; tab[i] = c; } init = true; }
+    uint32_t c = 0xFFFFFFFFu; const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; ++i) c = tab[(c ^ b[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+static std::pair<bool, Bytes> shim_robust(const float* cw, CodeRate rate, int* tries) {   // = robustDecodeSingleCW, see ref_robust_decode
+    LDPCDecoder decoder(rate);
+    decoder.setMaxIterations(fec::LDPCCodec::getRecommendedIterations(rate));
+    decoder.setMinSumFactor(0.9375f);
+    auto decoded = decoder.decodeSoft(std::span<const float>(cw, 648));
+    bool ok = decoder.lastDecodeSuccess();
+    int t = 1;
+    static constexpr float factors[] = {0.875f, 0.75f, 0.625f, 0.5f};
+    for (int retry = 0; retry < 4 && !ok; retry++) { decoder.setMinSumFactor(factors[retry]); decoded = decoder.decodeSoft(std::span<const float>(cw, 648)); ok = decoder.lastDecodeSuccess(); ++t; }
+    if (tries) *tries = t;
+    Bytes data; if (ok) data.assign(decoded.begin(), decoded.end());
+    return {ok, data};
+}
+// One data codeword (CW index 1 of a 2-CW frame) per trial, retransmitted until it decodes, as
+// StreamingDecoder::decodeMCDPSKFrame treats a CW >= 1 (streaming_decoder.cpp:2758-2800): robust decode of the fresh
+// reception; on failure ChaseCache::store + getCombined and, from the second reception on, robust decode of the sum.
+// Per transmission t of trial i: audio = MultiCarrierDPSKModulator(training + reference + modulate(LDPC R1/4 codeword)),
+// sim::WattersonChannel(preset, seeds[i*max_tx + t]), demodulator driven as after an external chirp detection.
+// Outputs per (trial, tx): crc32 of the 648 soft bits, crc32 of the cache sum after store (0 = not stored), robust tries of
+// the fresh and of the combined decode (0 = not made); per trial: transmissions to success (0 = never), decoded 20 bytes.
+int ref_harq_trials(int nc, int bps, int spreading, int kind, float snr_db, const uint8_t* info21, const uint32_t* seeds,
+                    int n_trials, int max_tx, int32_t* tx_to_success, uint32_t* llr_crc, uint32_t* acc_crc, int32_t* tries,
+                    uint8_t* decoded20, float* fading_out) {
+    ref_quiet();
+    sim::WattersonChannel::Config cc;
+    switch (kind) {
+        case 0: cc = sim::itu_r_f1487::awgn(snr_db); break;
+        case 1: cc = sim::itu_r_f1487::good(snr_db); break;
+        case 2: cc = sim::itu_r_f1487::moderate(snr_db); break;
+        case 3: cc = sim::itu_r_f1487::poor(snr_db); break;
+        default: cc = sim::itu_r_f1487::flutter(snr_db); break;
+    }
+    LDPCEncoder enc(CodeRate::R1_4);
+    fec::ChaseCache::Config chase_config;
+    chase_config.log_combines = false;
+    for (int i = 0; i < n_trials; ++i) {
+        fec::ChaseCache cache(chase_config);
+        fec::ChaseCacheKey key{static_cast<uint16_t>(i & 0xFFFF), 0x123456u, 0x654321u};
+        Bytes coded = enc.encode(ByteSpan(info21 + static_cast<size_t>(i) * 21, 21));
+        coded.resize(81);
+        MultiCarrierDPSKModulator m(mc_config(nc, bps, spreading));
+        Samples tr = m.generateTrainingSequence(), rf = m.generateReferenceSymbol(), dt = m.modulate(coded);
+        Samples tx; tx.insert(tx.end(), tr.begin(), tr.end()); tx.insert(tx.end(), rf.begin(), rf.end()); tx.insert(tx.end(), dt.begin(), dt.end());
+        tx_to_success[i] = 0;
+        std::memset(decoded20 + static_cast<size_t>(i) * 20, 0, 20);
+        for (int t = 0; t < max_tx; ++t) {
+            const size_t q = static_cast<size_t>(i) * max_tx + t;
+            llr_crc[q] = acc_crc[q] = 0; tries[2 * q] = tries[2 * q + 1] = 0;
+            if (tx_to_success[i]) continue;
+            sim::WattersonChannel ch(cc, seeds[q]);
+            Samples y = ch.process(SampleSpan(tx.data(), tx.size()));
+            MultiCarrierDPSKDemodulator d(mc_config(nc, bps, spreading));
+            d.setChirpDetected(0.0f);
+            d.setCFOWithPhase(0.0f, 0.0f);
+            if (!d.process(SampleSpan(y.data(), y.size()))) return -1;
+            if (fading_out) fading_out[q] = d.getFadingIndex();
+            std::vector<float> soft = d.getSoftBits();
+            if (soft.size() < 648) return -2;
+            soft.resize(648);
+            llr_crc[q] = crc32_bytes(soft.data(), 648 * sizeof(float));
+            auto [ok, data] = shim_robust(soft.data(), CodeRate::R1_4, &tries[2 * q]);
+            if (!ok) {
+                cache.store(key, 1, soft, 2, protocol::v2::FrameType::DATA);
+                auto combined = cache.getCombined(key, 1);
+                if (combined && combined->size() == 648) {
+                    acc_crc[q] = crc32_bytes(combined->data(), 648 * sizeof(float));
+                    if (cache.getCombineCount(key, 1) > 1) {
+                        auto [ok2, data2] = shim_robust(combined->data(), CodeRate::R1_4, &tries[2 * q + 1]);
+                        if (ok2 && data2.size() >= 20) { ok = true; data = std::move(data2); cache.markDecoded(key, 1); }
+                    }
+                }
+            }
+            if (ok && data.size() >= 20) {
+                std::memcpy(decoded20 + static_cast<size_t>(i) * 20, data.data(), 20);
+                tx_to_success[i] = t + 1;
+                cache.markDecoded(key, 1);
+            }
+        }
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------- burst chain

@@ -869,6 +869,18 @@ int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32
     return RIA_OK;
 }
 
+int ria_gpu_channel_exact_seeded_batch(ria_gpu_handle h, int kind, float snr_db, const uint32_t* seeds_dev, float* samples_dev,
+                                       int64_t stride, int frame_samples, int n_frames, void* stream) {
+    if (!h || n_frames < 0 || kind < 0 || kind > 4 || frame_samples < 0 || stride < frame_samples)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_seeded_batch: bad argument");
+    if (n_frames == 0 || frame_samples == 0) return RIA_OK;
+    if (!samples_dev || !seeds_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_seeded_batch: null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_channel_exact(kind, snr_db, 0u, 0u, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), seeds_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ debug
 __global__ void debug_math_kernel(int op, const float* a, const float* b, int n, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

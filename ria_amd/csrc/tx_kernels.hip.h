@@ -447,6 +447,7 @@ struct ChanExactArgs {
     int fading, multipath, delay;
     float alpha, one_minus_alpha, ns, g1, g2, noise_gain;
     uint32_t seed; uint64_t first_frame;
+    const uint32_t* seeds;   // nullable: per-frame mt19937 seeds (then seed / first_frame are not used)
 };
 __host__ __device__ inline int chan_exact_lds_bytes() { return 624 * 4 + kChanNbuf * 4 + 4 * kChanTile * 4 + kChanTile * 4 + 128 * 4 + 256 * 4 + 64; }
 
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
     power = __shfl(power, 0); cnt = __shfl(cnt, 0);
     const float rms = cnt ? fsqrt(fdiv(power, static_cast<float>(cnt))) : 0.1f;
     const float nstd = rms * A.noise_gain;
-    mt_seed_wave(st, A.seed + static_cast<uint32_t>(A.first_frame + blockIdx.x), lane);
+    mt_seed_wave(st, A.seeds ? A.seeds[blockIdx.x] : A.seed + static_cast<uint32_t>(A.first_frame + blockIdx.x), lane);
     for (int i = lane; i < 128; i += 64) hist[i] = 0.0f;
     int have = 0;
     const int per = A.fading ? 5 : 1;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
 }
 
 inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t first_frame, float* samples, long long stride,
-                                 int frame_samples, int n_frames, hipStream_t s) {
+                                 int frame_samples, int n_frames, hipStream_t s, const uint32_t* seeds = nullptr) {
     float delay_ms = 0, doppler = 0, g1 = 1.0f, g2 = 0.0f;  // presets hf_channel.hpp:411-488
     int fading = 1, multipath = 1;
     switch (kind) {
@@ -572,7 +573,7 @@ inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t
     A.ns = fading ? std::sqrt(1.0f / A.alpha) : 0.0f;
     A.g1 = g1; A.g2 = g2;
     A.noise_gain = powf(10.0f, -snr_db / 20.0f);
-    A.seed = seed; A.first_frame = first_frame;
+    A.seed = seed; A.first_frame = first_frame; A.seeds = seeds;
     hipLaunchKernelGGL(channel_exact_kernel, dim3(n_frames), dim3(64), chan_exact_lds_bytes(), s, A);
 }
 

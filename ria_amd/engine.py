@@ -298,6 +298,17 @@ class RxEngine:
                                                          _ptr(samples), fs, fs, n, _stream_ptr()))
         return samples
 
+    def channel_exact_seeded_(self, samples, kind, snr_db, seeds):
+        """Reference-identical channel with one mt19937 seed per frame: seeds uint32 tensor/array [n]; in place."""
+        n, fs = samples.shape
+        assert samples.dtype == torch.float32 and samples.is_contiguous()
+        if not torch.is_tensor(seeds):
+            seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32)).to(self.device)
+        assert seeds.numel() == n and seeds.element_size() == 4 and seeds.is_contiguous()
+        self._check(self.lib.ria_gpu_channel_exact_seeded_batch(self.h, int(kind), float(snr_db), _ptr(seeds), _ptr(samples), fs, fs, n,
+                                                                _stream_ptr()))
+        return samples
+
     def burst_deinterleave(self, llr, burst_frames):
         """BurstInterleaver::deinterleave: llr float32 [n_groups*N, >=2592] physical -> logical (same shape)."""
         n, stride = llr.shape

@@ -55,12 +55,29 @@ def reduce_counters(local, device):
     return t.cpu().numpy()
 
 
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
+    return x ^ (x >> np.uint64(31))
+
+
+def trial_seed32(base_seed, point_index, tx_no, trials):
+    """mt19937 seed of the channel of one transmission of one Monte-Carlo trial: a hash of (base seed, sweep point,
+    transmission number, GLOBAL trial index) folded to 32 bits - nothing else.  A trial's noise therefore does not
+    depend on the batch it is computed in, on which other trials already decoded, or on the number of GPUs."""
+    with np.errstate(over="ignore"):
+        t = np.asarray(trials, dtype=np.uint64)
+        h = _splitmix64(np.uint64(int(base_seed) & 0xFFFFFFFFFFFFFFFF) ^ _splitmix64(np.uint64(point_index) * np.uint64(0x10001) + np.uint64(tx_no) * np.uint64(0x1000000001)))
+        h = _splitmix64(h ^ _splitmix64(t))
+    return ((h >> np.uint64(32)) ^ (h & np.uint64(0xFFFFFFFF))).astype(np.uint32)
+
+
 def run_point_gpu(engine, point, base_seed, point_index, start, n):
     """One chunk of trials of one sweep point on this rank's GPU. Returns the counter row."""
-    first = point_index * (1 << 32) + start          # disjoint global frame indices per point
     info = engine.make_frames(base_seed, start, n)
     x = engine.tx(info, peak=0.8)
-    engine.channel_exact_(x, point.channel, point.snr_db, base_seed + 7919 * (point_index + 1), first_frame=first)
+    engine.channel_exact_seeded_(x, point.channel, point.snr_db, trial_seed32(base_seed, point_index, 0, np.arange(start, start + n)))
     out, st = engine.rx(x)
     s = engine.decode_status(st)
     ok = s["cw_ok"].all(axis=1) & s["frame_valid"].astype(bool)
@@ -88,7 +105,8 @@ def run_sweep(points, n_trials, base_seed, run_chunk, device, chunk=4096):
 # MC-DPSK rungs carry one R1/4 codeword per frame and retransmit failed codewords with HARQ chase combining
 # (fec::ChaseCache, <= 4 receptions, LLR sum); OFDM rungs are single shot.
 LADDER_COUNTERS = ("frames", "frame_err", "cw_err", "byte_err", "iters_sum", "transmissions")
-# typical measured fading index of the ITU-R F.1487 presets (thresholds 0.15 / 0.65 / 1.10, waveform_selection.hpp:49-61)
+# nominal fading index of the ITU-R F.1487 presets (thresholds 0.15 / 0.65 / 1.10, waveform_selection.hpp:49-61): only a
+# label for tables; the sweep feeds the ladder the demodulator's measured value (measured_fading_index)
 PRESET_FADING = {0: 0.05, 1: 0.45, 2: 0.90, 3: 1.20, 4: 1.40}
 _MOD_NAMES = {0: "DBPSK", 1: "BPSK", 2: "DQPSK", 3: "QPSK", 4: "D8PSK", 6: "QAM16", 7: "QAM32", 8: "QAM64", 10: "QAM256"}
 _RATE_NAMES = {0: "R1_4", 1: "R1_3", 2: "R1_2", 3: "R2_3", 4: "R3_4", 5: "R5_6"}
@@ -102,53 +120,203 @@ def ladder_mode(lib, snr_db, fading):
     return o
 
 
-def run_ladder_chunk(engines, point, base_seed, point_index, start, n, max_tx=4, n_payloads=32):
+def run_harq_trials(e, carriers, bps, spreading, kind, snr_db, info21, seeds, want_crc=False):
+    """The MC-DPSK data-codeword chain with HARQ chase combining on the GPU, per transmission exactly what
+    StreamingDecoder::decodeMCDPSKFrame does for a codeword >= 1 (streaming_decoder.cpp:2758-2800):
+      audio -> channel (seeds[i, t]) -> MC-DPSK demodulator -> robustDecodeSingleCW of the fresh soft bits;
+      on failure ChaseCache::store (copy / add) and, from the second reception on, robustDecodeSingleCW of the sum.
+    info21 uint8 [n, 21] (162 information bits), seeds uint32 [n, max_tx].  Returns a dict like oracle/pyoracle.py
+    Ref.harq_trials (the reference-side recorder): tx_to_success [n] (0 = never), decoded [n, 20], fading [n, max_tx],
+    tries [n, max_tx, 2], iterations_sum, and with want_crc the zlib.crc32 of every reception's soft bits / cache sum."""
+    import zlib
+    dev = e.device
+    info21 = np.ascontiguousarray(info21, np.uint8)
+    seeds = np.ascontiguousarray(seeds, np.uint32)
+    n, max_tx = seeds.shape
+    uniq, inv = np.unique(info21, axis=0, return_inverse=True)
+    coded = e.ldpc_encode(uniq)
+    frames = torch.from_numpy(np.stack([e.mcdpsk_modulate(coded[i], carriers, bps, spreading) for i in range(len(uniq))])).to(dev)
+    clean = frames[torch.from_numpy(np.asarray(inv).reshape(-1)).to(dev)]
+    acc = torch.zeros((n, 648), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    tts = np.zeros(n, np.int32)
+    decoded = np.zeros((n, 20), np.uint8)
+    llr_crc = np.zeros((n, max_tx), np.uint32); acc_crc = np.zeros((n, max_tx), np.uint32)
+    tries = np.zeros((n, max_tx, 2), np.int32); fading = np.zeros((n, max_tx), np.float32)
+    iters_sum = 0
+    for t in range(max_tx):
+        todo = np.nonzero(tts == 0)[0]
+        if len(todo) == 0:
+            break
+        td = torch.from_numpy(todo).to(dev)
+        x = clean[td].contiguous()
+        e.channel_exact_seeded_(x, kind, snr_db, seeds[todo, t])
+        llr, st = e.mcdpsk_demod(x, carriers, bps, spreading)
+        fading[todo, t] = st["fading_index"]
+        soft = llr[:, :648].contiguous()
+        o, ok, it, tr = e.ldpc_decode_robust(soft)
+        ok_h, tr_h = ok.cpu().numpy().astype(bool), tr.cpu().numpy()
+        iters_sum += int(it.to(torch.int64).sum().item())
+        tries[todo, t, 0] = tr_h
+        out_h = o.cpu().numpy()
+        if want_crc:
+            sh = soft.cpu().numpy()
+            llr_crc[todo, t] = [zlib.crc32(sh[q].tobytes()) for q in range(len(todo))]
+        failed = np.nonzero(~ok_h)[0]
+        if len(failed):
+            fd = td[torch.from_numpy(failed).to(dev)]
+            a, c = acc[fd].contiguous(), cnt[fd].contiguous()
+            e.chase_combine(a, c, soft[torch.from_numpy(failed).to(dev)].contiguous())   # ChaseCache::store: first reception copies, later ones add
+            acc[fd], cnt[fd] = a, c
+            if want_crc:
+                ah = a.cpu().numpy()
+                acc_crc[todo[failed], t] = [zlib.crc32(ah[q].tobytes()) for q in range(len(failed))]
+            if t > 0:                                                          # getCombineCount > 1
+                o2, ok2, it2, tr2 = e.ldpc_decode_robust(a)
+                iters_sum += int(it2.to(torch.int64).sum().item())
+                ok2_h = ok2.cpu().numpy().astype(bool)
+                tries[todo[failed], t, 1] = tr2.cpu().numpy()
+                ok_h[failed] = ok2_h
+                out_h[failed[ok2_h]] = o2.cpu().numpy()[ok2_h]
+        won = np.nonzero(ok_h)[0]
+        tts[todo[won]] = t + 1
+        decoded[todo[won]] = out_h[won][:, :20]
+    res = {"tx_to_success": tts, "decoded": decoded, "fading": fading, "tries": tries, "iterations_sum": iters_sum}
+    if want_crc:
+        res["llr_crc"], res["acc_crc"] = llr_crc, acc_crc
+    return res
+
+
+def trial_payloads(base_seed, point_index, trials, n_payloads=32):
+    """info bytes of every trial: one of n_payloads 162-bit messages of this point, picked by a hash of the global trial index"""
+    rng = np.random.default_rng([int(base_seed) & 0x7fffffff, int(point_index), 0x51])
+    pool = rng.integers(0, 256, (n_payloads, 21), dtype=np.uint8)
+    pool[:, -1] &= 0xC0                                   # k = 162 bits: the 21st byte carries 2 information bits
+    pick = (trial_seed32(base_seed, point_index, 255, trials) % np.uint32(n_payloads)).astype(np.int64)
+    return pool[pick]
+
+
+def measured_fading_index(engines, point, base_seed, point_index, n_probe=48):
+    """Fading index the ladder is fed with: the demodulator's own (MultiCarrierDPSKDemodulator::getFadingIndex, what the
+    host reads after the handshake frames), median over a fixed probe set of MC-DPSK DBPSK frames through this point's
+    channel.  The probe set is a function of (seed, point) only, so every rank computes the same value."""
+    e = engines("DQPSK", "R1_4")
+    probe = np.arange(n_probe)
+    info = trial_payloads(base_seed, point_index, probe, 4)
+    seeds = trial_seed32(base_seed, point_index, 254, probe)[:, None]
+    uniq, inv = np.unique(info, axis=0, return_inverse=True)
+    coded = e.ldpc_encode(uniq)
+    frames = torch.from_numpy(np.stack([e.mcdpsk_modulate(coded[i], 10, 1, 1) for i in range(len(uniq))])).to(e.device)
+    x = frames[torch.from_numpy(np.asarray(inv).reshape(-1)).to(e.device)].contiguous()
+    e.channel_exact_seeded_(x, point.channel, point.snr_db, seeds[:, 0])
+    _, st = e.mcdpsk_demod(x, 10, 1, 1)
+    return float(np.median(st["fading_index"]))
+
+
+def run_ladder_chunk(engines, point, base_seed, point_index, start, n, max_tx=4, n_payloads=32, fading=None):
     """One chunk of trials of one (channel, SNR) point with the mode the ladder picks.
-    engines: callable (mod_name, rate_name) -> RxEngine (cached by the caller)."""
+    engines: callable (mod_name, rate_name) -> RxEngine (cached by the caller).  fading: the fading index handed to
+    recommendWaveformAndRate (None: measured by the demodulator on this point's probe set)."""
     from . import capi
     lib = capi.load()
-    rec = ladder_mode(lib, point.snr_db, PRESET_FADING.get(point.channel, 0.9))
+    if fading is None:
+        fading = measured_fading_index(engines, point, base_seed, point_index)
+    rec = ladder_mode(lib, point.snr_db, fading)
     mod, rate = _MOD_NAMES[rec.modulation], _RATE_NAMES[rec.code_rate]
     e = engines(mod, rate)
     if rec.waveform != 4:   # OFDM-CHIRP rung: frame = 4 codewords, single shot
         row = run_point_gpu(e, point, base_seed, point_index, start, n)
         return np.array([row[0], row[1], row[2], row[3], row[4], n], dtype=np.int64)
-    # MC-DPSK rung: one R1/4 codeword (162 information bits) per frame, 10 carriers
+    # MC-DPSK rung: one R1/4 data codeword (162 information bits) per trial, 10 carriers, HARQ chase combining
+    e = engines("DQPSK", "R1_4") if rate != "R1_4" else e
     bps = 1 if rec.modulation == 0 else 2
-    sp = int(rec.spreading)
-    dev = e.device
-    rng = np.random.default_rng([int(base_seed) & 0x7fffffff, point_index, start])
-    info = rng.integers(0, 256, (n_payloads, 21), dtype=np.uint8)
-    info[:, -1] &= 0xC0                                   # k = 162 bits: the 21st byte carries 2 information bits
-    coded = e.ldpc_encode(info)
-    frames = np.stack([e.mcdpsk_modulate(coded[i], int(rec.num_carriers), bps, sp) for i in range(n_payloads)])
-    pick = torch.from_numpy(rng.integers(0, n_payloads, n)).to(dev)
-    clean = torch.from_numpy(frames).to(dev)[pick]                      # [n, samples]
-    info_t = torch.from_numpy(info).to(dev)[pick]
-    chan_seed = (int(base_seed) * 1000003 + point_index * 7919) & 0x7fffffff
-    acc = torch.zeros((n, 648), dtype=torch.float32, device=dev)
-    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
-    decoded = torch.zeros(n, dtype=torch.uint8, device=dev)
-    out = torch.zeros((n, 21), dtype=torch.uint8, device=dev)
-    iters_sum, transmissions = 0, 0
-    for tx_no in range(max_tx):
-        todo = (decoded == 0).nonzero().flatten()
-        if todo.numel() == 0:
-            break
-        transmissions += int(todo.numel())
-        # the reference channel model on the MC-DPSK audio (any frame length): a fresh stream per (transmission, trial)
-        x = clean[todo].contiguous()
-        e.channel_exact_(x, point.channel, point.snr_db, chan_seed + 104729 * tx_no, first_frame=start + int(todo[0].item()))
-        llr, _ = e.mcdpsk_demod(x, int(rec.num_carriers), bps, sp)
-        soft = llr[:, :648].contiguous()
-        a, c = acc[todo].contiguous(), cnt[todo].contiguous()
-        e.chase_combine(a, c, soft)                                     # first reception copies, later ones add
-        acc[todo], cnt[todo] = a, c
-        o, ok, it = e.ldpc_decode(a, 50, 0.9375)
-        iters_sum += int(it.to(torch.int64).sum().item())
-        good = ok.bool() & (o == info_t[todo]).all(dim=1)
-        out[todo] = o
-        decoded[todo] = torch.where(good, torch.ones_like(decoded[todo]), decoded[todo])
-    fail = int((decoded == 0).sum().item())
-    byte_err = int((out != info_t).sum().item())
-    return np.array([n, fail, fail, byte_err, iters_sum, transmissions], dtype=np.int64)
+    trials = np.arange(start, start + n)
+    info = trial_payloads(base_seed, point_index, trials, n_payloads)
+    seeds = np.stack([trial_seed32(base_seed, point_index, t, trials) for t in range(max_tx)], axis=1)
+    r = run_harq_trials(e, int(rec.num_carriers), bps, int(rec.spreading), point.channel, point.snr_db, info, seeds)
+    good = (r["tx_to_success"] > 0) & (r["decoded"] == info[:, :20]).all(axis=1)
+    transmissions = int(np.where(r["tx_to_success"] > 0, r["tx_to_success"], max_tx).sum())
+    fail = int((~good).sum())
+    byte_err = int((r["decoded"] != info[:, :20]).sum())
+    return np.array([n, fail, fail, byte_err, r["iterations_sum"], transmissions], dtype=np.int64)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Acquisition grid (BASELINE.json config 4): ZC + dual-chirp preambles in noise over a CFO x SNR grid.
+def analytic(x):
+    X = torch.fft.fft(x.double(), dim=-1)
+    n = x.shape[-1]
+    h = torch.zeros(n, dtype=torch.float64, device=x.device)
+    h[0] = 1
+    h[1:(n + 1) // 2] = 2
+    if n % 2 == 0:
+        h[n // 2] = 1
+    return torch.fft.ifft(X * h, dim=-1)
+
+
+def make_acq_buffers(pre, n, buf_len, max_off, snr_db, cfo_hz, gen, dev):
+    """pre: 1-D preamble tensor on dev.  Returns (buffers float32 [n, buf_len], offsets): the preamble at a random
+    offset in a noise-padded buffer, CFO by analytic-signal rotation, AWGN from the preamble's rms."""
+    L = pre.numel()
+    seg = pre
+    if cfo_hz != 0.0:
+        t = torch.arange(L, device=dev, dtype=torch.float64) / 48000.0
+        seg = (analytic(pre) * torch.exp(2j * np.pi * cfo_hz * t)).real.float()
+    rms = pre[pre != 0].pow(2).mean().sqrt()
+    sigma = rms * 10.0 ** (-snr_db / 20.0)
+    buf = torch.randn((n, buf_len), generator=gen, device=dev) * sigma
+    offs = torch.randint(0, max_off + 1, (n,), generator=gen, device=dev)
+    idx = offs[:, None] + torch.arange(L, device=dev)[None, :]
+    buf.scatter_add_(1, idx, seg[None, :].expand(n, -1).contiguous())
+    return buf.contiguous(), offs
+
+
+ACQ_GRID = [(c, s) for c in (-50.0, -25.0, 0.0, 25.0, 50.0) for s in (-10.0, -5.0, 0.0, 5.0, 10.0)]
+ACQ_COUNTERS = ("n", "zc_detected", "zc_timing_ok", "chirp_success", "chirp_timing_ok", "chirp_cfo_ok")
+
+
+def run_acquisition_grid(engine, dev, cdev, preambles, seed, kinds=None, grid=None, sync=None):
+    """Preambles are dealt to the ranks in fixed-size chunks (chunk c of a (grid point, kind) goes to rank c % world) and
+    every chunk draws its buffers from its own generator seeded by (seed, grid point, kind, chunk index): the counters do
+    not depend on the number of ranks.  The only collectives are the all-reduce of the counters and of the wall times
+    (cdev: where those few bytes live - the GPU for RCCL, the CPU for gloo).
+    kinds: [(name, preamble tensor, buffer length, largest offset, chunk)]; returns (counters [len(grid), 6], [t_zc, t_chirp])."""
+    import time
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    grid = ACQ_GRID if grid is None else grid
+    sync = sync or (lambda: None)
+    cnt = torch.zeros((len(grid), 6), dtype=torch.int64, device=dev)
+    t_zc = t_ch = 0.0
+    for gi, (cfo, snr) in enumerate(grid):
+        for ki, (kind, pre, buf_len, max_off, chunk) in enumerate(kinds):
+            for start, n in shard_range(preambles, rank, world, chunk):
+                gen = torch.Generator(device=dev)
+                gen.manual_seed((int(seed) * 1000003 + gi * 8191 + ki * 131 + start // chunk) & 0x7FFFFFFFFFFFFFFF)
+                buf, offs = make_acq_buffers(pre, n, buf_len, max_off, snr, cfo, gen, dev)
+                sync()
+                t0 = time.perf_counter()
+                if kind == "zc":
+                    # ZC alone is unambiguous to +-23.6 Hz (zc_sync.hpp:55-58): the chirp's CFO is handed to it as known_cfo
+                    r = engine.sync_zc(buf, 0.3, 15, torch.full((n,), cfo, dtype=torch.float32, device=dev))
+                    t_zc += time.perf_counter() - t0
+                    det = torch.from_numpy(r["detected"].astype(np.int64)).to(dev)
+                    ok = (torch.from_numpy(r["start_sample"].astype(np.int64)).to(dev) - (offs + pre.numel())).abs() <= 4
+                    cnt[gi, 0] += n
+                    cnt[gi, 1] += det.sum()
+                    cnt[gi, 2] += (det.bool() & ok).sum()
+                else:
+                    r = engine.sync_chirp(buf, 0.15)
+                    t_ch += time.perf_counter() - t0
+                    suc = torch.from_numpy(r["success"].astype(np.int64)).to(dev)
+                    ok = (torch.from_numpy(r["up_chirp_start"].astype(np.int64)).to(dev) - offs).abs() <= 2
+                    cok = torch.from_numpy(np.abs(r["cfo_hz"] - cfo) <= 1.0).to(dev)
+                    cnt[gi, 3] += suc.sum()
+                    cnt[gi, 4] += (suc.bool() & ok).sum()
+                    cnt[gi, 5] += (suc.bool() & cok).sum()
+    cnt = cnt.to(cdev)
+    tt = torch.tensor([t_zc, t_ch], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return cnt.cpu().numpy(), tt.cpu().numpy()

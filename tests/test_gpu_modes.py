@@ -257,3 +257,82 @@ def test_robust_single_cw_decode_vs_reference_golden(golden):
         assert np.array_equal(it.cpu().numpy(), r[:, 2].astype(np.int16)), rn
         nb = out.shape[1]
         assert np.array_equal(out.cpu().numpy(), r[:, 3:3 + nb].astype(np.uint8)), rn
+
+
+def test_harq_chain_vs_reference_golden(golden):
+    """BASELINE config 5, MC-DPSK rungs (DBPSK 4x / 2x / no spreading, DQPSK) at two marginal SNRs each plus two faded
+    cases, 192 trials per case: MC-DPSK modulator -> reference-identical channel (per-trial seeds) -> demodulator ->
+    robustDecodeSingleCW -> ChaseCache::store -> robustDecodeSingleCW of the sum, up to 4 transmissions.  Per trial the
+    number of transmissions to success, per reception the checksum of the 648 soft bits and of the cache sum, the decoder
+    tries, the decoded bytes and the demodulator's fading index: all identical to what the reference's own classes
+    produced (tests/golden/harq_trials.npz, recorded by oracle/ref_shim.cpp ref_harq_trials)."""
+    import gen_golden
+    from ria_amd import sweep
+    e = engine("DQPSK", "R1_4")
+    g = golden("harq_trials")
+    for i, (nc, bps, sp, kind, snr) in enumerate(gen_golden.HARQ_CASES):
+        info, seeds = gen_golden.harq_inputs(i)
+        r = sweep.run_harq_trials(e, nc, bps, sp, kind, snr, info, seeds, want_crc=True)
+        for k in ("tx_to_success", "llr_crc", "acc_crc", "tries", "decoded"):
+            bad = np.nonzero((r[k] != g[f"{k}_{i}"]).reshape(len(info), -1).any(axis=1))[0]
+            assert len(bad) == 0, f"case {i} {gen_golden.HARQ_CASES[i]}: {k} differs for trials {bad[:6]}"
+        m = r["llr_crc"] != 0
+        assert np.array_equal(r["fading"][m].view(np.uint32), g[f"fading_{i}"][m].view(np.uint32)), (i, "fading index")
+    # a trial's outcome is a function of (seed, point, trial) only: any sub-batch reproduces its rows
+    info, seeds = gen_golden.harq_inputs(6)
+    sub = np.array([5, 17, 18, 40, 101, 190])
+    r = sweep.run_harq_trials(e, 10, 2, 1, 0, -12.0, info[sub], seeds[sub])
+    assert np.array_equal(r["tx_to_success"], g["tx_to_success_6"][sub]) and np.array_equal(r["decoded"], g["decoded_6"][sub])
+
+
+def test_adaptive_ladder_sweep_table():
+    """BASELINE config 5 end to end on one GPU at reduced trials: 3 channels x SNR -14..30 dB step 2 = 69 points, the
+    ladder (recommendWaveformAndRate fed with the demodulator's measured fading index) picks the rung, MC-DPSK rungs run
+    the HARQ chain above, OFDM rungs the fused RX.  Assertions = the reference's own operating-point claims
+    (waveform_selection.hpp:88-111): on AWGN every rung is clean from its floor upwards (4x spreading from -14 dB, 2x from
+    -8, none from -4, MC-DPSK DQPSK from +5, OFDM from 10 dB), the picked rungs are the table's, HARQ is exercised only
+    below the floors, fading never makes a point better than AWGN by more than noise."""
+    from ria_amd import sweep, capi
+    from ria_amd.engine import RxEngine
+    cache = {}
+
+    def engines(mod, rate):
+        if (mod, rate) not in cache:
+            cache[(mod, rate)] = RxEngine(mod, rate, max_batch=256)
+        return cache[(mod, rate)]
+
+    lib = capi.load()
+    trials, seed = 64, 4321
+    snrs = np.arange(-14.0, 30.1, 2.0)
+    rows, modes, fad = {}, {}, {}
+    pi = 0
+    for ch in (0, 1, 2):
+        for snr in snrs:
+            p = sweep.SweepPoint(ch, float(snr))
+            fad[(ch, snr)] = sweep.measured_fading_index(engines, p, seed, pi)
+            rec = sweep.ladder_mode(lib, snr, fad[(ch, snr)])
+            modes[(ch, snr)] = (rec.waveform, rec.modulation, rec.code_rate, rec.spreading)
+            rows[(ch, snr)] = sweep.run_ladder_chunk(engines, p, seed, pi, 0, trials, fading=fad[(ch, snr)])
+            pi += 1
+    assert pi == 69
+    for snr in snrs:                       # AWGN: measured fading index below the 0.15 "true AWGN" threshold at usable SNR
+        if snr >= 10:
+            assert fad[(0, snr)] < 0.15, (snr, fad[(0, snr)])
+    # the rungs the table prescribes on AWGN
+    assert modes[(0, -14.0)] == (4, 0, 0, 4) and modes[(0, -8.0)] == (4, 0, 0, 4) and modes[(0, -6.0)] == (4, 0, 0, 2)
+    assert modes[(0, -2.0)] == (4, 0, 0, 1) and modes[(0, 6.0)][:3] == (4, 2, 0) and modes[(0, 26.0)][:3] == (5, 8, 4)
+    assert modes[(0, 22.0)][:3] == (5, 7, 4) and modes[(0, 18.0)][:2] == (5, 6) and modes[(0, 12.0)][:2] == (5, 2)
+    for snr in snrs:
+        r = rows[(0, snr)]
+        assert r[0] == trials
+        assert r[1] == 0, f"AWGN {snr} dB {modes[(0, snr)]}: {r[1]} of {trials} trials failed above the rung's floor"
+        if modes[(0, snr)][0] == 4:
+            assert r[5] == trials, f"AWGN {snr} dB: HARQ retransmissions above the floor"
+    for ch in (1, 2):
+        for snr in snrs:
+            r = rows[(ch, snr)]
+            assert r[0] == trials and r[5] >= trials
+            if modes[(ch, snr)][0] == 4 and snr >= -4:
+                assert r[1] <= trials // 4, (ch, snr, r)
+    fer = {k: v[1] / trials for k, v in rows.items()}
+    print("ladder table:", {f"{k[0]}:{k[1]:+.0f}": (modes[k], round(fad[k], 2), round(fer[k], 3), round(rows[k][5] / trials, 2)) for k in rows})

@@ -302,3 +302,53 @@ def test_robust_single_cw_oracle_matches_reference_golden(oracle, golden):
             ok, out, it, tries = oracle.robust_decode(rate, llr)
             assert (int(ok), tries, it) == (int(r[0]), int(r[1]), int(r[2])), (rate, r[:3], ok, tries, it)
             assert np.array_equal(out, r[3:3 + len(out)].astype(np.uint8))
+
+
+def oracle_harq_trials(oracle, nc, bps, sp, kind, snr, info21, seeds):
+    """The MC-DPSK data-codeword chain with HARQ chase combining (streaming_decoder.cpp:2758-2800) on the CPU
+    restatement: modulate -> channel(seed) -> demod -> robust decode; on failure ChaseCache::store and, from the second
+    reception on, robust decode of the sum."""
+    import zlib
+    n, max_tx = seeds.shape
+    out = {"tx_to_success": np.zeros(n, np.int32), "llr_crc": np.zeros((n, max_tx), np.uint32), "acc_crc": np.zeros((n, max_tx), np.uint32),
+           "tries": np.zeros((n, max_tx, 2), np.int32), "decoded": np.zeros((n, 20), np.uint8), "fading": np.zeros((n, max_tx), np.float32)}
+    for i in range(n):
+        coded = oracle.ldpc_encode(po.R1_4, info21[i])
+        tx = oracle.mcdpsk_modulate(nc, bps, sp, coded)
+        acc, count = np.zeros(648, np.float32), np.zeros(1, np.int32)
+        for t in range(max_tx):
+            y = oracle.channel(kind, snr, int(seeds[i, t]), tx)
+            llr, aux = oracle.mcdpsk_demod(nc, bps, sp, y)
+            soft = np.ascontiguousarray(llr[:648])
+            out["fading"][i, t] = aux[1]
+            out["llr_crc"][i, t] = zlib.crc32(soft.tobytes())
+            ok, data, it, tries = oracle.robust_decode(po.R1_4, soft)
+            out["tries"][i, t, 0] = tries
+            if not ok:
+                oracle.lib.ro_chase_store(po.fp(acc), po.ip(count), 0, po.fp(soft))
+                out["acc_crc"][i, t] = zlib.crc32(acc.tobytes())
+                if count[0] > 1:
+                    ok, data, it, tries = oracle.robust_decode(po.R1_4, acc)
+                    out["tries"][i, t, 1] = tries
+            if ok:
+                out["tx_to_success"][i] = t + 1
+                out["decoded"][i] = data[:20]
+                break
+    return out
+
+
+def test_harq_chain_oracle_matches_reference_golden(oracle, golden):
+    """Config 5, MC-DPSK rungs: transmissions-to-success, every reception's soft bits (checksum), every cache sum, decoder
+    tries and decoded bytes of the first trials of each case, against the reference's own modulator / WattersonChannel /
+    demodulator / ChaseCache / LDPCDecoder chain (tests/golden/harq_trials.npz)."""
+    import gen_golden
+    oracle.lib.ro_chase_store.argtypes = [po._f, po._i, po.C.c_int, po._f]
+    g = golden("harq_trials")
+    for i, (nc, bps, sp, kind, snr) in enumerate(gen_golden.HARQ_CASES):
+        n = 10 if i in (0, 6, 9) else 3
+        info, seeds = gen_golden.harq_inputs(i, n)
+        r = oracle_harq_trials(oracle, nc, bps, sp, kind, snr, info, seeds)
+        for k in ("tx_to_success", "llr_crc", "acc_crc", "tries", "decoded"):
+            assert np.array_equal(r[k], g[f"{k}_{i}"][:n]), (i, k)
+        m = r["llr_crc"] != 0
+        assert np.array_equal(r["fading"][m].view(np.uint32), g[f"fading_{i}"][:n][m].view(np.uint32)), (i, "fading")

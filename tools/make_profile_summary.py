@@ -4,7 +4,14 @@ profiles/<tag>_* files.  usage: tools/make_profile_summary.py <tag> <stats_dir> 
 import collections, csv, glob, json, os, shutil, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from ria_amd.srchash import csrc_sha256  # noqa: E402
+# the PMC passes run `bench.py --steps-only --steps 1 --warmup 1`: two whole steps and nothing else on the GPU
+META = {"tag": None, "source_sha256": csrc_sha256(), "steps_counted": 2, "frames_per_step": 25000, "frames_per_launch": 25000,
+        "note": "source_sha256 = sha256 over ria_amd/csrc/* at the time of the measurement (ria_amd/srchash.py); bench.py quotes "
+                "these figures only while the sources are unchanged"}
 tag, stats_dir, fetch_dir, write_dir, sq_dir, bench_json = sys.argv[1:7]
+META["tag"] = tag
 P = os.path.join(root, "profiles")
 
 
@@ -39,7 +46,9 @@ for k in f:
         fe = f[k]["FETCH_SIZE"] / nf[k]; wr = w.get(k, {}).get("WRITE_SIZE", 0.0) / max(1, nw.get(k, 1))
         # rocprofv3 reports KB; gfx950: FETCH_SIZE tallies 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM section)
         traffic[k] = {"launches": nf[k], "fetch_kb_raw": round(fe, 1), "write_kb_raw": round(wr, 1), "hbm_bytes_per_launch": round(fe * 1024 * 2 + wr * 1024)}
+traffic["_meta"] = META
 json.dump(traffic, open(os.path.join(P, f"{tag}_hbm_traffic_pmc.json"), "w"), indent=1)
+del traffic["_meta"]
 a, n, dur = agg(one(os.path.join(sq_dir, "*", "*counter_collection.csv")), {"SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU", "SQ_INSTS_LDS"})
 sq = {}
 for k, v in a.items():
@@ -50,13 +59,15 @@ for k, v in a.items():
              "lds_busy_frac": round(v["SQ_LDS_IDX_ACTIVE"] / n[k] / (256 * cyc), 3),
              "lds_bank_conflict_share": round(v["SQ_LDS_BANK_CONFLICT"] / max(1.0, v["SQ_LDS_IDX_ACTIVE"]), 3),
              "valu_insts": v["SQ_INSTS_VALU"] / n[k], "lds_insts": v["SQ_INSTS_LDS"] / n[k]}
+sq["_meta"] = META
 json.dump(sq, open(os.path.join(P, f"{tag}_sq_utilisation_pmc.json"), "w"), indent=1)
+del sq["_meta"]
 rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_bench_kernel_stats.csv"))))
 L = [f"# {tag} — bench, kernel trace and PMC summaries\n",
      "Commands (MI355X box, repo root, after `cd /tmp && export TMPDIR=/tmp`):\n",
      f"* `python bench.py` -> `{tag}_bench.json`",
      f"* `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` -> `{tag}_bench_kernel_stats.csv`",
-     f"* `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1`, same with `WRITE_SIZE` (separate passes) -> `{tag}_hbm_traffic_pmc.json` (both passes with `RIA_NO_SPLIT=1`, so one launch = one whole 25 000-frame step, the unit `bench.py`'s roofline uses; FETCH_SIZE x 2 for gfx950; Infinity-Cache hits are counted)",
+     f"* `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps-only --steps 1 --warmup 1`, same with `WRITE_SIZE` (separate passes) -> `{tag}_hbm_traffic_pmc.json` (both passes with `RIA_NO_SPLIT=1`, so one launch = one whole 25 000-frame step, the unit `bench.py`'s roofline uses; FETCH_SIZE x 2 for gfx950; Infinity-Cache hits are counted)",
      f"* `rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py ...` -> `{tag}_sq_utilisation_pmc.json`\n",
      f"Bench line: **{bench['value']:.0f} frames/s** on 1 MI355X ({bench['ms_per_step']} ms per 25 000-frame step); reference CPU path on the same box: {bench['cpu_baseline']['value']} frames/s on {bench['cpu_baseline']['cores']} threads ({bench['cpu_baseline']['kind']}).\n",
      "| kernel | calls | avg ms | % of GPU time |", "|---|---|---|---|"]

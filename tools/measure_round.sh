@@ -9,10 +9,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
 step() { local name=$1; shift; "$@"; local rc=$?; echo "$name rc=$rc" | tee -a "$O/progress.log"; if [ $rc -ge 124 ]; then exit $rc; fi; }
 run_pytest() { timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$O/pytest_gpu.log" 2>&1; }
+run_latency() { timeout -k 10 300 python tools/bench_latency.py --out "$O/latency.json" > "$O/latency.log" 2>&1; }
 run_smoke() { timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; }
 run_bench() { timeout -k 10 400 python bench.py > "$O/bench.log" 2>&1; }
 run_stats() { timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 bench.py --no-cpu-baseline > "$O/stats.log" 2>&1; }
-run_pmc() { local d=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$O/$d" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > "$O/$d.log" 2>&1; }
+run_pmc() { local d=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$O/$d" -- python3 bench.py --steps-only --steps 1 --warmup 1 > "$O/$d.log" 2>&1; }
 run_sync() { timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/sync" -- python3 tools/bench_sync.py > "$O/sync.log" 2>&1; }
 step pytest run_pytest; tail -2 "$O/pytest_gpu.log"
 step smoke run_smoke
@@ -24,4 +25,5 @@ step write run_pmc write WRITE_SIZE
 unset RIA_NO_SPLIT
 step sq run_pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 step sync run_sync
+step latency run_latency
 ls "$O"

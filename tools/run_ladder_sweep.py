@@ -55,8 +55,9 @@ def main():
         lib = capi.load()
         table = []
         for p, r in zip(points, total):
-            rec = sweep.ladder_mode(lib, p.snr_db, sweep.PRESET_FADING.get(p.channel, 0.9))
-            table.append({"channel": p.channel, "snr_db": p.snr_db, "waveform": int(rec.waveform), "modulation": int(rec.modulation),
+            fad = sweep.measured_fading_index(engines, p, args.seed, len(table))
+            rec = sweep.ladder_mode(lib, p.snr_db, fad)
+            table.append({"channel": p.channel, "snr_db": p.snr_db, "measured_fading_index": round(fad, 3), "waveform": int(rec.waveform), "modulation": int(rec.modulation),
                           "code_rate": int(rec.code_rate), "spreading": int(rec.spreading), "frames": int(r[0]), "frame_err": int(r[1]),
                           "fer": round(float(r[1]) / max(1, int(r[0])), 5), "mean_transmissions": round(float(r[5]) / max(1, int(r[0])), 3)})
         print(json.dumps({"config": "adaptive ladder sweep with HARQ", "n_gpus": world, "trials_per_point": args.trials,
