@@ -125,8 +125,8 @@ def run_harq_trials(e, carriers, bps, spreading, kind, snr_db, info21, seeds, wa
     StreamingDecoder::decodeMCDPSKFrame does for a codeword >= 1 (streaming_decoder.cpp:2758-2800):
       audio -> channel (seeds[i, t]) -> MC-DPSK demodulator -> robustDecodeSingleCW of the fresh soft bits;
       on failure ChaseCache::store (copy / add) and, from the second reception on, robustDecodeSingleCW of the sum.
-    info21 uint8 [n, 21] (162 information bits), seeds uint32 [n, max_tx].  Returns a dict like oracle/pyoracle.py
-    Ref.harq_trials (the reference-side recorder): tx_to_success [n] (0 = never), decoded [n, 20], fading [n, max_tx],
+    info21 uint8 [n, 21] (162 information bits), seeds uint32 [n, max_tx].  Returns a dict shaped like the one the tests record from
+    the reference with (tests/golden/harq_trials.npz): tx_to_success [n] (0 = never), decoded [n, 20], fading [n, max_tx],
     tries [n, max_tx, 2], iterations_sum, and with want_crc the zlib.crc32 of every reception's soft bits / cache sum."""
     import zlib
     dev = e.device
