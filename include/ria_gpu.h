@@ -132,6 +132,9 @@ int  ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out);
  *                        streams (1..4; 1 = one stream, no overlap; 0 = library default, which the environment
  *                        variables RIA_SPLIT_PARTS / RIA_NO_SPLIT may override). */
 #define RIA_OPT_SPLIT_PARTS 1
+/*   RIA_OPT_DUAL_DECODER the retry kernels (phase 0, cascade) decode two codewords per wavefront on an interleaved LDS
+ *                        image (ldpc_dual.hip.h): 1 = on, -1 = off, 0 = library default (off; RIA_DUAL=1 turns it on). */
+#define RIA_OPT_DUAL_DECODER 2
 int  ria_gpu_set_option(ria_gpu_handle h, int option, int value);
 
 /* ---- RX: demodulate  (IWaveform::process + getSoftBits, waveform_interface.hpp:124,135;

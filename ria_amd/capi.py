@@ -12,6 +12,7 @@ DECODE_PHASE0, DECODE_PERTURB, DECODE_CRC_RECOVER, DECODE_FULL = 1, 2, 4, 7
 DECODE_NO_CHANNEL_DEINTERLEAVE = 0x100
 RX_DEMOD_ONLY = 0x200
 OPT_SPLIT_PARTS = 1
+OPT_DUAL_DECODER = 2
 
 # every symbol include/ria_gpu.h declares
 EXPORTS = [

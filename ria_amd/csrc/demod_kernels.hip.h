@@ -127,29 +127,34 @@ __device__ __forceinline__ float minf_(float a, float b) { return (b < a) ? b : 
 // scatter their N terms to LDS rows compacted by ordinal (member o -> T[k][o]); lane k then adds row k
 // front to back (contiguous 16-byte LDS reads, `count` dependent adds) while the other N-1 sums run
 // in the neighbouring lanes; results are broadcast with readlane.
-// Non-members / ordinals >= count contribute nothing (the accumulator starts at +0 and never becomes -0).
+// Entries at ordinals >= count hold +0.0 (the scratch is zeroed at kernel start, members only ever write ordinals
+// < count, and the one call with a larger count clears its tail afterwards): the accumulator starts at +0.0 and can
+// never become -0.0 (x + y is -0.0 only for two negative zeros), so the trailing "+ 0.0f" adds are exact identities and
+// the row is summed without any per-term test.
 constexpr int kSumRow = 68;
-template <int N, int MAXC>
+constexpr int kPilotRow = 20;   // the pilot-ordered sums (<= 16 terms) have their own scratch: rows 20 floats apart
+template <int N, int MAXC, int ROW = kSumRow>
 __device__ __forceinline__ void ordered_sums(const float (&terms)[N], bool member, int ord, int count, float* T,
                                              int lane, float (&out)[N]) {
-    static_assert(N <= 8 && MAXC % 4 == 0 && MAXC <= 64, "scratch is [8][kSumRow]");
+    static_assert(N <= 8 && MAXC % 4 == 0 && MAXC <= ROW - 4, "scratch is [8][ROW]");
+    (void)count;
     if (member) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) T[k * kSumRow + ord] = terms[k];
+        for (int k = 0; k < N; ++k) T[k * ROW + ord] = terms[k];
     }
     wave_sync();
-    // rows are 68 floats apart: a stride of 64 would put the 8 rows read by one ds_read_b128 on the same banks
-    const float4* row = reinterpret_cast<const float4*>(T + (lane & 7) * kSumRow);
+    // rows are 68 (20) floats apart: a stride of 64 (16) would put the 8 rows read by one ds_read_b128 on the same banks
+    const float4* row = reinterpret_cast<const float4*>(T + (lane & 7) * ROW);
     float4 v[MAXC / 4];
 #pragma unroll
     for (int q = 0; q < MAXC / 4; ++q) v[q] = row[q];
     float acc = 0.0f;
 #pragma unroll
     for (int q = 0; q < MAXC / 4; ++q) {
-        acc = (4 * q + 0 < count) ? acc + v[q].x : acc;
-        acc = (4 * q + 1 < count) ? acc + v[q].y : acc;
-        acc = (4 * q + 2 < count) ? acc + v[q].z : acc;
-        acc = (4 * q + 3 < count) ? acc + v[q].w : acc;
+        acc = acc + v[q].x;
+        acc = acc + v[q].y;
+        acc = acc + v[q].z;
+        acc = acc + v[q].w;
     }
 #pragma unroll
     for (int k = 0; k < N; ++k)
@@ -370,15 +375,16 @@ __device__ __forceinline__ float2 hard_decision(float2 s, int mod) {  // channel
 
 // ---------------------------------------------------------------- the frame kernel
 constexpr int kDemodThreads = 64;   // ONE wavefront per frame: no workgroup barriers, no idle waves in phase E
-// LDS per frame: 1 FFT tile (8.7 KB) + Y[n_sym][64] bins + small shared state (~19 KB at 16 symbols)
-constexpr int kMaxSymbols = 40;  // 2 LTS + up to 38 data symbols (DBPSK R1/4 needs 2592/53 = 49 -> see launch check)
-
+// The frame is streamed symbol by symbol (FFT of symbol s, then the estimator step that consumes it), so the LDS
+// holds one FFT tile (8.7 KB), THREE rows of bins (the two training symbols + the current one) and the scratch of the
+// ordered sums: 13.1 KB per frame whatever the frame length -> 12 frames per CU (3 waves per SIMD).
 struct DemodShared {
     float cfo, theta0;          // current CFO and correction phase at frame start
     int rerun, pad_;
-    float sym_theta[64];        // correction phase at the first sample of each symbol
-    float sub_theta[16];        // ... and at every 72nd sample of the symbol being staged
-    float sums[8 * 68];         // ordered_sums scratch [8][kSumRow] (16-byte aligned: see offset of this member)
+    float th_end, pad2_[3];     // correction phase after the last sample of the frame
+    float sub_theta[16];        // correction phase at every 72nd sample of the symbol being staged
+    float sums[8 * kSumRow];    // ordered_sums scratch [8][kSumRow], data- and carrier-ordered sums (16-byte aligned)
+    float psums[8 * kPilotRow]; // ordered_sums scratch of the pilot-ordered sums
 };
 
 // One step of the CFO correction phase (channel_equalizer.cpp:139-144): th += inc, wrapped with
@@ -410,75 +416,72 @@ __device__ __forceinline__ float cfo_phase_step8(float th, float inc) {
     return t8;
 }
 
-__device__ __forceinline__ void demod_fft_phase(const DemodArgs& A, const DemodConst& K, const float* __restrict__ x,
-                                       int n_sym, float2* buf, float2* Y, DemodShared* sh, int lane) {
+// Symbol s of the frame: CFO correction phases (if any), downconversion, FFT; the 59 used bins go to Yrow.
+// th_walk (meaningful on lane 0): correction phase at the first sample of this symbol on entry, of the next on exit.
+__device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float* __restrict__ x, int s, float2* buf, float2* Yrow,
+                                                 DemodShared* sh, int lane, float& th_walk) {
     const float cfo = sh->cfo;
     const bool use_cfo = fabs_(cfo) > 0.01f;
     const float inc = static_cast<float>(-2.0f * 3.14159265358979323846 * static_cast<double>(cfo) / 48000.0);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
-    float th_walk = sh->theta0;   // lane 0: correction phase at the start of the next symbol
-    for (int s = 0; s < n_sym; ++s) {
-        float th_reg[16];
-        if (use_cfo) {
-            // channel_equalizer.cpp:132-144: float phase recurrence over EVERY sample (CP included), wrapped
-            // with double-precision pi.  Inherently serial: lane 0 walks the symbol once, dropping a
-            // marker every 72 samples; 16 lanes then re-walk 72 samples each into the (still free) tile.
-            float* thb = reinterpret_cast<float*>(buf);
-            if (lane == 0) {
-                float th = th_walk;
-                for (int q = 0; q < 16; ++q) {
-                    sh->sub_theta[q] = th;
+    float th_reg[16];
+    if (use_cfo) {
+        // channel_equalizer.cpp:132-144: float phase recurrence over EVERY sample (CP included), wrapped
+        // with double-precision pi.  Inherently serial: lane 0 walks the symbol once, dropping a
+        // marker every 72 samples; 16 lanes then re-walk 72 samples each into the (still free) tile.
+        float* thb = reinterpret_cast<float*>(buf);
+        if (lane == 0) {
+            float th = th_walk;
+            for (int q = 0; q < 16; ++q) {
+                sh->sub_theta[q] = th;
 #pragma unroll 1
-                    for (int g = 0; g < 9; ++g) th = cfo_phase_step8(th, inc);
-                }
-                th_walk = th;
+                for (int g = 0; g < 9; ++g) th = cfo_phase_step8(th, inc);
             }
-            wave_sync();
-            if (lane < 16) {
-                float th = sh->sub_theta[lane];
-                for (int i = 0; i < 72; ++i) { thb[72 * lane + i] = th; th = cfo_phase_step(th, inc); }
-            }
-            wave_sync();
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) th_reg[4 * c + e] = thb[kCP + 4 * lane + 256 * c + e];
-            wave_sync();
-        }
-        // stage + downconvert 1024 samples (cyclic prefix dropped): 16 B per lane per load, coalesced
-        const float* xs = x + s * kSym + kCP;
-        const float2* osc = A.nco + s * kSym + kCP;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int j = 4 * lane + 256 * c;
-            float xv[4];
-            if (aligned) { float4 v = *reinterpret_cast<const float4*>(xs + j); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
-            else { xv[0] = xs[j]; xv[1] = xs[j + 1]; xv[2] = xs[j + 2]; xv[3] = xs[j + 3]; }
-            const float4 o01 = *reinterpret_cast<const float4*>(osc + j), o23 = *reinterpret_cast<const float4*>(osc + j + 2);
-            const float2 ov[4] = {make_float2(o01.x, o01.y), make_float2(o01.z, o01.w), make_float2(o23.x, o23.y), make_float2(o23.z, o23.w)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float2 m = make_float2(xv[e] * ov[e].x, xv[e] * -ov[e].y);  // samples[i] * conj(osc)
-                if (use_cfo) m = cmul(m, cexpj(th_reg[4 * c + e]));
-                buf[j + e] = m;
-            }
+            th_walk = th;
         }
         wave_sync();
-        fft1024_wave(buf, A.twiddle, Y + s * 64, lane);
+        if (lane < 16) {
+            float th = sh->sub_theta[lane];
+            for (int i = 0; i < 72; ++i) { thb[72 * lane + i] = th; th = cfo_phase_step(th, inc); }
+        }
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) th_reg[4 * c + e] = thb[kCP + 4 * lane + 256 * c + e];
+        wave_sync();
     }
-    if (lane == 0) sh->sym_theta[n_sym] = th_walk;
+    // stage + downconvert 1024 samples (cyclic prefix dropped): 16 B per lane per load, coalesced
+    const float* xs = x + s * kSym + kCP;
+    const float2* osc = A.nco + s * kSym + kCP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int j = 4 * lane + 256 * c;
+        float xv[4];
+        if (aligned) { float4 v = *reinterpret_cast<const float4*>(xs + j); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+        else { xv[0] = xs[j]; xv[1] = xs[j + 1]; xv[2] = xs[j + 2]; xv[3] = xs[j + 3]; }
+        const float4 o01 = *reinterpret_cast<const float4*>(osc + j), o23 = *reinterpret_cast<const float4*>(osc + j + 2);
+        const float2 ov[4] = {make_float2(o01.x, o01.y), make_float2(o01.z, o01.w), make_float2(o23.x, o23.y), make_float2(o23.z, o23.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float2 m = make_float2(xv[e] * ov[e].x, xv[e] * -ov[e].y);  // samples[i] * conj(osc)
+            if (use_cfo) m = cmul(m, cexpj(th_reg[4 * c + e]));
+            buf[j + e] = m;
+        }
+    }
     wave_sync();
+    fft1024_wave(buf, A.twiddle, Yrow, lane);
 }
 
-__global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A) {
+__global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3))) void demod_frames_kernel(DemodArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DemodConst& K = *A.k;
     const int lane = threadIdx.x;
     const int frame = blockIdx.x;
     const int n_sym = 2 + K.n_data_symbols;
     float2* tiles = reinterpret_cast<float2*>(smem);                       // 1088 float2
-    float2* Y = tiles + kFftBufFloats2;                                    // [n_sym][64]
-    DemodShared* sh = reinterpret_cast<DemodShared*>(Y + static_cast<size_t>(n_sym) * 64);
+    float2* Y = tiles + kFftBufFloats2;                                    // [3][64]: training symbols 0, 1 and the current data symbol
+    DemodShared* sh = reinterpret_cast<DemodShared*>(Y + 3 * 64);
 
     const float* x = A.samples + (A.offsets ? A.offsets[frame] : static_cast<uint64_t>(frame) * n_sym * kSym);
     if (threadIdx.x == 0) {
@@ -500,6 +503,9 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
         sh->theta0 = static_cast<float>(init);
         sh->rerun = 0;
     }
+    // ordered-sum scratch: +0.0 everywhere (see ordered_sums)
+    for (int i = lane; i < 8 * kSumRow; i += 64) sh->sums[i] = 0.0f;
+    for (int i = lane; i < 8 * kPilotRow; i += 64) sh->psums[i] = 0.0f;
     wave_sync();
     const bool negate_lts0 = A.meta && (A.meta[frame].flags & 1u);
 
@@ -515,15 +521,19 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
     const bool is_dat = is_car && !K.is_pilot[lane];
     const int my_ord = K.ord[lane];          // data ordinal (data carriers) / pilot ordinal (pilots)
     float* T = sh->sums;
+    float* TP = sh->psums;
+    float th_walk = 0.0f;
     const float2 txv = make_float2(K.tx_re[lane], K.tx_im[lane]);
     const float lsign = negate_lts0 ? -1.0f : 1.0f;
     float2 H0 = make_float2(0, 0), H1 = make_float2(0, 0);
 
     // ================= LTS channel estimate (channel_equalizer.cpp:193-643), possibly twice
     for (int pass = 0; pass < 2; ++pass) {
-        // ---- phase F: all symbols through the FFT with the current CFO (pass 1: mixer.reset(), phase
+        // ---- the two training symbols through the FFT with the current CFO (pass 1: mixer.reset(), phase
         // restored to its value at training start, corrected CFO: channel_equalizer.cpp:337-344)
-        demod_fft_phase(A, K, x, n_sym, tiles, Y, sh, lane);
+        th_walk = sh->theta0;
+        demod_fft_symbol(A, x, 0, tiles, Y, sh, lane, th_walk);
+        demod_fft_symbol(A, x, 1, tiles, Y + 64, sh, lane, th_walk);
         if (A.dbg && pass == 0) t1 = __builtin_readcyclecounter();
         {
             float2 y0 = Y[0 * 64 + lane], y1 = Y[1 * 64 + lane];
@@ -569,6 +579,9 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             float tr = v ? fdiv(diff.x, mag) : 0.0f, ti = v ? fdiv(diff.y, mag) : 0.0f;
             float o2[2];
             { const float t2[2] = {tr, ti}; ordered_sums<2, 60>(t2, lane < kCarriers - 1, lane, kCarriers - 1, T, lane, o2); }
+            // the only call ordered by carrier (58 terms): give the entries beyond the data ordinals their +0.0 back
+            if (lane >= K.n_data) { T[lane] = 0.0f; T[kSumRow + lane] = 0.0f; }
+            wave_sync();
             const float sr = o2[0], si = o2[1];
             int cnt = __popcll(__ballot(v));
             if (cnt > 0) slope = atan2f_glibc(fdiv(si, static_cast<float>(cnt)), fdiv(sr, static_cast<float>(cnt)));
@@ -621,7 +634,8 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
         const float2 rot_res = make_float2(cosf_glibc(ph_res), sinf_glibc(ph_res));
 
         for (int ds = 0; ds < K.n_data_symbols; ++ds) {
-            float2 y = Y[(2 + ds) * 64 + lane];
+            demod_fft_symbol(A, x, 2 + ds, tiles, Y + 128, sh, lane, th_walk);
+            float2 y = Y[128 + lane];
             const bool first = (ds == 0);
             // ---------- updateChannelEstimate (channel_equalizer.cpp:645-1043)
             if (K.n_pilot > 0) {
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                     cp_init = true;
                 } else if (!cp_init) {
                     float o2[2];
-                    { const float t2[2] = {hls.x, hls.y}; ordered_sums<2, 16>(t2, is_pil, my_ord, K.n_pilot, T, lane, o2); }
+                    { const float t2[2] = {hls.x, hls.y}; ordered_sums<2, 16, kPilotRow>(t2, is_pil, my_ord, K.n_pilot, TP, lane, o2); }
                     float2 hsum = make_float2(o2[0], o2[1]);
                     float2 havg = make_float2(fdiv(hsum.x, npf), fdiv(hsum.y, npf));
                     float am = cabs_(havg);
@@ -651,7 +665,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 {
                     const float t6[6] = {v ? fdiv(ratio.x, mag) * hm : 0.0f, v ? fdiv(ratio.y, mag) * hm : 0.0f,
                                          v ? hm : 0.0f, cnorm(hls), nvv ? cnorm(dp) : 0.0f, hls_abs};
-                    ordered_sums<6, 16>(t6, is_pil, my_ord, K.n_pilot, T, lane, o6);
+                    ordered_sums<6, 16, kPilotRow>(t6, is_pil, my_ord, K.n_pilot, TP, lane, o6);
                 }
                 if (coh) {  // common phase error
                     const float cr = o6[0], ci = o6[1], ws = o6[2];
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                     float mean = fdiv(o6[5], npf);
                     float df = hls_abs - mean;
                     float o1[1];
-                    { const float t1[1] = {df * df}; ordered_sums<1, 16>(t1, is_pil, my_ord, K.n_pilot, T, lane, o1); }
+                    { const float t1[1] = {df * df}; ordered_sums<1, 16, kPilotRow>(t1, is_pil, my_ord, K.n_pilot, TP, lane, o1); }
                     float vv = fdiv(o1[0], npf);
                     fading = (mean > 0.01f) ? fdiv(fsqrt(vv), mean) : 0.0f;
                 }
@@ -817,6 +831,8 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
                 }
             }
         }
+        if (lane == 0) sh->th_end = th_walk;
+        wave_sync();
         if (A.status && lane == 0) {
             ria_frame_status st;
             // 10*log10f(x): the only transcendental on the status path that is not bit-pinned; it is
@@ -827,7 +843,7 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
             st.noise_variance = noise_var;
             st.lts_phase_slope = slope;
             st.snr_linear = snr_lin;
-            st.corr_phase = (fabs_(sh->cfo) > 0.01f) ? sh->sym_theta[n_sym] : sh->theta0;
+            st.corr_phase = (fabs_(sh->cfo) > 0.01f) ? sh->th_end : sh->theta0;
             st.n_llr = K.n_llr;
             A.status[frame] = st;
         }
@@ -839,7 +855,8 @@ __global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(DemodArgs A
 }
 
 inline int demod_lds_bytes(int n_sym) {
-    return kFftBufFloats2 * 8 + n_sym * 64 * 8 + static_cast<int>(sizeof(DemodShared)) + 16;
+    (void)n_sym;   // streamed: independent of the frame length
+    return kFftBufFloats2 * 8 + 3 * 64 * 8 + static_cast<int>(sizeof(DemodShared)) + 16;
 }
 inline hipError_t demod_set_attributes() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(demod_frames_kernel),

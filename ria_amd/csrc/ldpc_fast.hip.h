@@ -274,7 +274,10 @@ __device__ __forceinline__ float llr_canon(float x) {
 //   column pass  tot[j] = llr[j] + sum of its c2v slots in ascending check order -> ONE store per column.
 // Zeros stay canonical: x - y and x + y only give -0.0 from (-0.0, +-0.0) operands, the LLRs are
 // canonical and a c2v of -0.0 can only be added to or subtracted from a canonical value.
-template <class S, int NCV = (kCvRegs ? 1024 : 0)>
+#ifndef RIA_SINGLE_PREFETCH
+#define RIA_SINGLE_PREFETCH 2
+#endif
+template <class S, int NCV = (kCvRegs ? 1024 : 0), int PF = RIA_SINGLE_PREFETCH>
 __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned char* __restrict__ lds,
                                   float factor, int max_iter, int lane, bool* ok) {
     using I = ShapeInfo<S>;
@@ -304,14 +307,26 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
     bool success = false;
     for (; it < max_iter; ++it) {
         uint32_t syn = 0;
+        // the total gathers of round r + PF are issued before round r is computed (LDS operations keep their program
+        // order: without this every round starts by waiting out an LDS round trip)
+        float tt[I::TS];
+        auto gather_round = [&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value;
+            if constexpr (g < S::NR) {
+#pragma unroll
+                for (int s = 0; s < S::ne(g); ++s) tt[I::row_off(g) + s] = lds_f(st.rv[I::row_off(g) + s]);
+            }
+        };
+        static_for<0, PF>([&](auto G_) __attribute__((always_inline)) { gather_round(G_); });
         static_for<0, S::NR>([&](auto R_) __attribute__((always_inline)) {
             constexpr int r = decltype(R_)::value;
             constexpr int NE = S::ne(r);
             constexpr int off = I::row_off(r);
+            gather_round(std::integral_constant<int, r + PF>{});
             float t[NE], cold[NE];
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
-                t[s] = lds_f(st.rv[off + s]);
+                t[s] = tt[off + s];
                 if (off + s < NCV) cold[s] = st.cv[off + s];
                 else cold[s] = lds_f(lane4 + 256u * (off + s));
             }
@@ -664,10 +679,10 @@ __global__ void fast_chain_kernel(FastDecodeArgs A) {
 // perturbed decoder input of cascade attempt a (frame_v2.cpp:1415-1546) into st.li/st.lp
 template <class S>
 __device__ inline float fast_perturb(FastState<S>& st, const FastCode& c, const float* base_i, const float* base_p,
-                                     uint32_t* mt, float* normal, int a, uint32_t h, int lane) {
+                                     uint32_t* mt, float* normal, int a, uint32_t h, int lane, bool exp_skip_rng = false) {
     uint32_t seed; float sigma, factor; int kind;
     retry_transform_params(a, h, &seed, &sigma, &factor, &kind);
-    normal648_wave(mt, normal, seed, lane);
+    if (!exp_skip_rng) normal648_wave(mt, normal, seed, lane);   // exp_skip_rng: timing experiment only (tools/exp_*)
     auto tf = [&](float v, float nz) {
         if (kind == 1) { v = (v < 10.0f) ? v : 10.0f; v = (-10.0f < v) ? v : -10.0f; }
         else if (kind == 2) v = v * 0.5f;
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
 #pragma unroll
         for (int r = 0; r < S::NR; ++r) bp[r] = st.lp[r];
         const uint32_t h = A.l1hash[li];
-        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
+        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane, (A.flags & 0x8000u) != 0);
         bool ok;
         const int it = fast_decode<S, S::kCascadeCv>(st, c, smem, factor, c.max_iter, lane, &ok);
         if (ok) {

@@ -26,6 +26,9 @@ __device__ __forceinline__ void wave_sync() {
 // state: 624 words in LDS.  Seeding is a serial recurrence (lane 0); the twist runs in three
 // data-independent chunks across the lanes; the Marsaglia polar rejection consumes draws in aligned
 // pairs, so acceptance is decided per pair in parallel and ranked with a ballot prefix count.
+// W: word stride of the state / output arrays (2 = every other dword: one component of the dual decoder's
+// interleaved LDS image, ldpc_dual.hip.h)
+template <int W = 1>
 __device__ inline void mt_seed_wave(uint32_t* st, uint32_t seed, int lane) {
     // The seeding recurrence is serial, so it runs on the SCALAR unit: the value is wave-uniform (readfirstlane
     // tells the compiler), the 4 ops per step are s_lshr/s_xor/s_mul/s_add and issue beside other waves'
@@ -44,14 +47,15 @@ __device__ inline void mt_seed_wave(uint32_t* st, uint32_t seed, int lane) {
             // lane select through M0: a second SGPR operand would exceed the constant-bus limit of one
             asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(x), "s"(j) : "m0");
         }
-        if (r < 9 || lane < 624 - 576) st[64 * r + lane] = reg;
+        if (r < 9 || lane < 624 - 576) st[(64 * r + lane) * W] = reg;
     }
     wave_sync();
 }
+template <int W = 1>
 __device__ inline void mt_twist_wave(uint32_t* st, int lane) {
     auto step = [&](int i, int a, int b) {
-        uint32_t y = (st[i] & 0x80000000u) | (st[a] & 0x7fffffffu);
-        uint32_t v = st[b] ^ (y >> 1);
+        uint32_t y = (st[i * W] & 0x80000000u) | (st[a * W] & 0x7fffffffu);
+        uint32_t v = st[b * W] ^ (y >> 1);
         if (y & 1u) v ^= 0x9908b0dfu;
         return v;
     };
@@ -60,7 +64,7 @@ __device__ inline void mt_twist_wave(uint32_t* st, int lane) {
         uint32_t v = 0;
         if (i < 227) v = step(i, i + 1, i + 397);
         wave_sync();
-        if (i < 227) st[i] = v;
+        if (i < 227) st[i * W] = v;
         wave_sync();
     }
     for (int base = 227; base < 623; base += 64) {
@@ -68,10 +72,10 @@ __device__ inline void mt_twist_wave(uint32_t* st, int lane) {
         uint32_t v = 0;
         if (i < 623) v = step(i, i + 1, i - 227);
         wave_sync();
-        if (i < 623) st[i] = v;
+        if (i < 623) st[i * W] = v;
         wave_sync();
     }
-    if (lane == 0) st[623] = step(623, 0, 396);
+    if (lane == 0) st[623 * W] = step(623, 0, 396);
     wave_sync();
 }
 __device__ __forceinline__ float mt_canonical(uint32_t y) {  // tempering + generate_canonical<float,24>
@@ -83,18 +87,19 @@ __device__ __forceinline__ float mt_canonical(uint32_t y) {  // tempering + gene
     return (r >= 1.0f) ? u2f(0x3f7fffffu) : r;
 }
 // Fills normal[0..647] with the first 648 values of normal_distribution<float>(0,1) on mt19937(seed).
+template <int W = 1>
 __device__ inline void normal648_wave(uint32_t* st, float* normal, uint32_t seed, int lane) {
-    mt_seed_wave(st, seed, lane);
+    mt_seed_wave<W>(st, seed, lane);
     int accepted = 0;  // accepted pairs so far (wave-uniform)
     while (accepted < 324) {
-        mt_twist_wave(st, lane);
+        mt_twist_wave<W>(st, lane);
         for (int base = 0; base < 312 && accepted < 324; base += 64) {
             int p = base + lane;
             bool acc = false;
             float x = 0.f, y = 0.f, r2 = 1.f;
             if (p < 312) {
-                x = 2.0f * mt_canonical(st[2 * p]) - 1.0f;
-                y = 2.0f * mt_canonical(st[2 * p + 1]) - 1.0f;
+                x = 2.0f * mt_canonical(st[(2 * p) * W]) - 1.0f;
+                y = 2.0f * mt_canonical(st[(2 * p + 1) * W]) - 1.0f;
                 r2 = x * x + y * y;
                 acc = !(r2 > 1.0f || r2 == 0.0f);
             }
@@ -102,8 +107,8 @@ __device__ inline void normal648_wave(uint32_t* st, float* normal, uint32_t seed
             int q = accepted + __popcll(mask & ((1ull << lane) - 1ull));
             if (acc && q < 324) {
                 float mult = fsqrt(fdiv(-2.0f * logf_glibc(r2), r2));
-                normal[2 * q] = y * mult;      // returned first
-                normal[2 * q + 1] = x * mult;  // the saved value, returned by the next call
+                normal[(2 * q) * W] = y * mult;      // returned first
+                normal[(2 * q + 1) * W] = x * mult;  // the saved value, returned by the next call
             }
             accepted += __popcll(mask);
         }

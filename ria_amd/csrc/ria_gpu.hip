@@ -22,6 +22,7 @@
 #include "frame_recovery.hpp"
 #include "ldpc_kernels.hip.h"
 #include "ldpc_fast.hip.h"
+#include "ldpc_dual.hip.h"
 #include "recovery_kernels.hip.h"
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
@@ -75,6 +76,7 @@ struct ria_gpu {
     unsigned int* d_l1hash = nullptr;     // [4 * ws_frames]
     int ws_frames = 0;
     int split_parts = 0;                  // RIA_OPT_SPLIT_PARTS (0 = library default)
+    int dual_decoder = 0;                 // RIA_OPT_DUAL_DECODER: 0 = default (environment RIA_DUAL, else off), 1 = on, -1 = off
     // host-buffer entry points (the single-frame IWaveform adaptor path): one device + one pinned staging block and a
     // stream, kept for the life of the handle, grown on demand - no allocation and no device-wide sync per call
     unsigned char* d_hstage = nullptr; unsigned char* p_hstage = nullptr; size_t hstage_bytes = 0; hipStream_t hstream = nullptr;
@@ -180,6 +182,8 @@ static void set_fast_attributes(int rate, int wb) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_robust_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, DualInfo<S>::lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, DualInfo<S>::lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(recovery_fill_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
     });
 }
@@ -530,6 +534,7 @@ int ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out) {
 int ria_gpu_set_option(ria_gpu_handle h, int option, int value) {
     if (!h) return RIA_ERR_INVALID;
     if (option == RIA_OPT_SPLIT_PARTS && value >= 0 && value <= kMaxParts) { h->split_parts = value; return RIA_OK; }
+    if (option == RIA_OPT_DUAL_DECODER && value >= -1 && value <= 1) { h->dual_decoder = value; return RIA_OK; }
     return fail(h, RIA_ERR_INVALID, "ria_gpu_set_option: unknown option %d or value %d out of range", option, value);
 }
 
@@ -581,7 +586,8 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.llr = llr_dev;
     A.llr_stride = llr_stride;
     A.n_frames = n_frames;
-    A.flags = flags;
+    A.flags = flags & 0x7fffu;
+    if (getenv("RIA_EXP_NO_RNG")) A.flags |= 0x8000u;   // developer timing experiment: wrong results
     A.info_out = info_out_dev;
     A.status = status_dev;
     A.crc_bit = static_cast<const uint16_t*>(h->d_crc_bit);
@@ -599,6 +605,13 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     if ((e = hipMemsetAsync(A.ctl, 0, sizeof(DecodeCtl), s)) != hipSuccess)
         return fail(h, RIA_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const int wb = h->wave_lds;
+    // RIA_OPT_DUAL_DECODER / RIA_DUAL=1: the retry kernels decode two codewords per wave (ldpc_dual.hip.h) on 2 waves per
+    // SIMD instead of one codeword per wave on 3.  Same results (tested); measured slower on the bench workload
+    // (DESIGN.md section 4), so it is not the default.
+    static const bool dual_env = getenv("RIA_DUAL") && getenv("RIA_DUAL")[0] == '1';
+    const bool dual = h->dual_decoder > 0 || (h->dual_decoder == 0 && dual_env);
+    static const int grid_env = getenv("RIA_PERSIST_GRID") ? std::max(64, atoi(getenv("RIA_PERSIST_GRID"))) : 0;
+    const int persist_grid = grid_env ? grid_env : (dual ? 2048 : 3072);
     static const bool dbg = getenv("RIA_DEBUG_SYNC") != nullptr;   // stage-by-stage sync + trace on stderr
     auto stage = [&](const char* name) {
         if (!dbg) return;
@@ -616,14 +629,17 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
             hipLaunchKernelGGL(fast_stage_kernel<S>, dim3(std::min(4 * n_frames, 8192)), dim3(256), 0, s, A);
             stage("stage");
         }
-        if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB))
-            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, 3072)), dim3(64), wb, s, A);
+        if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB)) {
+            if (dual) hipLaunchKernelGGL(dual_phase0_kernel<S>, dim3(std::min(n_frames * 8, persist_grid)), dim3(64), DualInfo<S>::lds_bytes, s, A);
+            else hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, persist_grid)), dim3(64), wb, s, A);
+        }
         stage("phase0");
         hipLaunchKernelGGL(fast_chain_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
         stage("chain");
         if (flags & RIA_DECODE_PERTURB) {
             // persistent waves over the device-side work list; sized to fill the chip (256 CUs x 12)
-            hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(3072), dim3(64), wb, s, A);
+            if (dual) hipLaunchKernelGGL(dual_cascade_kernel<S>, dim3(persist_grid), dim3(64), DualInfo<S>::lds_bytes, s, A);
+            else hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(persist_grid), dim3(64), wb, s, A);
             stage("cascade");
             hipLaunchKernelGGL(fast_finalize_kernel, dim3(std::min((4 * n_frames + 255) / 256, 1024)), dim3(256), 0, s, A);
             stage("finalize");

@@ -61,6 +61,10 @@ class RxEngine:
         """How many parts ria_gpu_rx_batch cuts a large batch into (internal streams); 0 = library default."""
         self._check(self.lib.ria_gpu_set_option(self.h, capi.OPT_SPLIT_PARTS, int(parts)))
 
+    def set_dual_decoder(self, mode):
+        """1: two codewords per wave in the retry kernels, -1: one, 0: library default"""
+        self._check(self.lib.ria_gpu_set_option(self.h, capi.OPT_DUAL_DECODER, int(mode)))
+
     # ---- helpers
     def _meta(self, n, cfo_hz, abs_pos, flags):
         if cfo_hz is None and abs_pos is None and flags is None:

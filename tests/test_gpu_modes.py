@@ -44,6 +44,14 @@ def test_rx_batch_split_modes_are_bit_identical_and_match_the_reference(oracle):
             out, st = e.rx(x)
             torch.cuda.synchronize()
             runs.setdefault(parts, []).append((out.cpu().numpy().copy(), e.decode_status(st).copy()))
+    # the two-codewords-per-wave retry kernels (ldpc_dual.hip.h) on the same batch, one stream and the default split
+    for parts in (1, 0):
+        e.set_split_parts(parts)
+        e.set_dual_decoder(1)
+        out, st = e.rx(x)
+        torch.cuda.synchronize()
+        runs.setdefault(("dual", parts), []).append((out.cpu().numpy().copy(), e.decode_status(st).copy()))
+    e.set_dual_decoder(0)
     base_out, base_st = runs[1][0]
     for parts, lst in runs.items():
         for rep, (o, s) in enumerate(lst):

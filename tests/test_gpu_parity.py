@@ -139,6 +139,11 @@ def test_decode_fixed_frame_vs_reference_golden(golden, oracle, name):
         d, ok, iters, att = oracle.decode_fixed_frame(g["llr"][f], int(g["rate"]), True, int(g["bps"]), flags=7)
         assert np.array_equal(s["iterations"][f], iters.astype(np.uint16))
         assert np.array_equal(s["attempts"][f], att.astype(np.uint8))
+    # the two-codewords-per-wave retry kernels (ldpc_dual.hip.h, every code rate's shape): identical in every field
+    e.set_dual_decoder(1)
+    info2, st2 = e.decode(dev(g["llr"]))
+    e.set_dual_decoder(0)
+    assert np.array_equal(info2.cpu().numpy(), info) and np.array_equal(st2.cpu().numpy(), st.cpu().numpy())
 
 
 def test_rx_fused_matches_oracle_random_frames(oracle):
