@@ -126,12 +126,18 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
 // CRC-16/CCITT-FALSE (ControlFrame::calculateCRC, frame_v2.cpp:115-128) of d[0..L) by one wave.
 __device__ inline uint32_t crc16_wave(const uint8_t* d, int L, const uint16_t* crc_bit, const uint16_t* crc_init,
                                       int lane) {
+    // the eight per-bit syndromes of a byte are one aligned 16-byte load (the table is indexed by distance from the
+    // end of the message, bit-major inside a byte); selected by the byte's bits without a branch
     uint32_t acc = 0;
     for (int i = lane; i < L; i += 64) {
-        int b = d[i], q0 = (L - 1 - i) * 8;
+        const uint32_t b = d[i];
+        const uint4 w = *reinterpret_cast<const uint4*>(crc_bit + (L - 1 - i) * 8);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (b & (1 << t)) acc ^= crc_bit[q0 + t];
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t e = (t & 1) ? (ws[t >> 1] >> 16) : (ws[t >> 1] & 0xffffu);
+            acc ^= (b & (1u << t)) ? e : 0u;
+        }
     }
     return (wave_xor(acc) ^ crc_init[L]) & 0xffffu;
 }

@@ -29,6 +29,9 @@ struct RecCtx {            // wave-uniform view of one frame's working set (all 
     Suspect* sus;          // [4 * bpc * 8]
     int* stack;            // [192]
     uint16_t* sd;          // [32]
+    uint16_t* lists;       // [2][sus_cap / 2 + 32] position lists of the partition passes
+    int sus_cap;           // suspects the LDS array holds (rec_search returns kRecOverflow if a frame has more)
+    unsigned long long* dbg;   // nullable: 8 cycle stamps of this frame's search (developer diagnostics)
     int bpc;
     const uint16_t* crc_bit;
     const uint16_t* crc_init;
@@ -87,10 +90,125 @@ __device__ inline void rec_flip(const RecCtx& x, int byte_index, int bit) {   //
     wave_sync();
 }
 
+// ---- std::sort of the suspects, first 30 positions, by the whole wave (sort_exact.hpp: sort_exact_prefix_lists) ------
+// One __unguarded_partition_pivot pass over v[first, last): median of three to v[first], then the two-list rule - the
+// positions whose key is not below the pivot (ascending) and those whose key is not above it (descending) are ranked
+// with ballot prefix counts, swap k exchanges the rank-k members of the two lists while they have not crossed.
+// scratch: chunk masks in x.fd / x.trial (free during the sort), the two position lists in x.lists.
+__device__ inline int rec_partition_wave(const RecCtx& x, int first, int last) {
+    Suspect* v = x.sus;
+    const int lane = x.lane;
+    const int mid = first + (last - first) / 2;
+    const float ka = v[first + 1].abs_llr, kb = v[mid].abs_llr, kc = v[last - 1].abs_llr;
+    int pick;
+    if (ka < kb) { pick = (kb < kc) ? mid : (ka < kc) ? last - 1 : first + 1; }
+    else { pick = (ka < kc) ? first + 1 : (kb < kc) ? last - 1 : mid; }
+    wave_sync();
+    if (lane == 0) { const Suspect t = v[first]; v[first] = v[pick]; v[pick] = t; }
+    wave_sync();
+    const float pk = v[first].abs_llr;
+    const int d0 = first + 1, m = last - first - 1, nch = (m + 63) >> 6;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(x.fd);   // [nch][2]: not-below / not-above the pivot
+    uint16_t* alist = x.lists;
+    uint16_t* blist = x.lists + x.sus_cap / 2 + 32;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+    int ns_total = 0;
+    for (int c = 0; c < nch; ++c) {
+        const int t = 64 * c + lane;
+        const float key = (t < m) ? v[d0 + t].abs_llr : 0.0f;
+        const unsigned long long mb = __ballot(t < m && !(key < pk)), ms = __ballot(t < m && !(pk < key));
+        if (lane == 0) { masks[2 * c] = mb; masks[2 * c + 1] = ms; }
+        ns_total += __popcll(ms);
+    }
+    wave_sync();
+    // number of swaps: a not-below element of left rank a is swapped iff more than a not-above elements lie to its right
+    int kk = 0, base_b = 0, base_s = 0;
+    for (int c = 0; c < nch; ++c) {
+        const unsigned long long mb = masks[2 * c], ms = masks[2 * c + 1];
+        const int a = base_b + __popcll(mb & lt_mask), s_le = base_s + __popcll(ms & le_mask);
+        kk += __popcll(__ballot(((mb >> lane) & 1ull) != 0ull && ns_total - s_le > a));
+        base_b += __popcll(mb); base_s += __popcll(ms);
+    }
+    // the rank lists of the swapped elements, and the first not-below element that is not swapped (if any)
+    const int kBig = 0x7fffffff;
+    int t_a = kBig;
+    base_b = 0; base_s = 0;
+    for (int c = 0; c < nch; ++c) {
+        const unsigned long long mb = masks[2 * c], ms = masks[2 * c + 1];
+        const int t = 64 * c + lane;
+        const bool boe = ((mb >> lane) & 1ull) != 0ull, soe = ((ms >> lane) & 1ull) != 0ull;
+        const int a = base_b + __popcll(mb & lt_mask), b = ns_total - (base_s + __popcll(ms & le_mask));
+        if (boe && a < kk) alist[a] = static_cast<uint16_t>(t);
+        if (soe && b < kk) blist[b] = static_cast<uint16_t>(t);
+        const unsigned long long here = __ballot(boe && a == kk);
+        if (here) t_a = 64 * c + __builtin_ctzll(here);
+        base_b += __popcll(mb); base_s += __popcll(ms);
+    }
+    wave_sync();
+    for (int k = lane; k < kk; k += 64) {
+        const int i = d0 + alist[k], j = d0 + blist[k];
+        const Suspect t = v[i]; v[i] = v[j]; v[j] = t;
+    }
+    const int t_b = (kk > 0) ? static_cast<int>(blist[kk - 1]) : kBig;
+    wave_sync();
+    return d0 + (t_a < t_b ? t_a : t_b);
+}
+__device__ inline void rec_sort_suspects_wave(const RecCtx& x, int n, int want) {
+    if (n <= 0) return;
+    Suspect* v = x.sus;
+    const int lane = x.lane;
+    const int limit = (want >= n) ? n : want + 16;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    int sp = 1;
+    if (lane == 0) { x.stack[0] = 0; x.stack[1] = n; x.stack[2] = 2 * lg; }
+    wave_sync();
+    while (sp > 0) {
+        --sp;
+        int first = x.stack[3 * sp], last = x.stack[3 * sp + 1], depth = x.stack[3 * sp + 2];
+        while (last - first > 16) {
+            if (first >= limit) break;
+            if (depth == 0) {   // libstdc++ falls back to heapsort (rare): serial, as before
+                wave_sync();
+                if (lane == 0) sortx::heap_sort(v + first, v + last, suspect_lt);
+                wave_sync();
+                break;
+            }
+            --depth;
+            const int cut = rec_partition_wave(x, first, last);
+            if (cut < limit) {
+                if (lane == 0) { x.stack[3 * sp] = cut; x.stack[3 * sp + 1] = last; x.stack[3 * sp + 2] = depth; }
+                ++sp;
+                wave_sync();
+            }
+            last = cut;
+        }
+    }
+    // __final_insertion_sort over the first `fin` <= 46 positions = a stable sort of them: one lane per element
+    const int fin = (limit < n) ? limit : n;
+    wave_sync();
+    Suspect mine = {0, 0.0f};
+    if (lane < fin) mine = v[lane];
+    int rank = 0;
+    for (int j = 0; j < fin; ++j) {
+        const float kj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.abs_llr), j));
+        rank += (kj < mine.abs_llr || (j < lane && !(mine.abs_llr < kj))) ? 1 : 0;
+    }
+    wave_sync();
+    if (lane < fin) v[rank] = mine;
+    wave_sync();
+}
+
 // Stage 1 (frame_v2.cpp:1579-1834).  llr(c, i): decoder-order LLR i of codeword c.
+// Returns 1 (recovered), 0 (not), or kRecOverflow: more suspects than the LDS array holds - nothing has been modified,
+// the caller hands the frame to the big-LDS instance of the kernel.
+constexpr int kRecOverflow = 2;
+constexpr int kRecSmallCap = 320;     // suspects in the common instance's LDS (2.5 KB instead of 4*bpc*8 entries)
 template <class LlrFn>
-__device__ inline bool rec_search(const RecCtx& x, LlrFn llr) {
+__device__ inline int rec_search(const RecCtx& x, LlrFn llr) {
     const int bpc = x.bpc, lane = x.lane;
+    auto stamp = [&](int k) { if (x.dbg && lane == 0) x.dbg[k] = __builtin_readcyclecounter(); };
+    stamp(0);
     const int flen = rec_reassemble(x, x.fd);
     if (flen == 0) {
         // case 1: header CRC error in CW0.  hdr_ok() = magic bytes match && CRC(bytes 0..14) == bytes 15..16;
@@ -156,10 +274,18 @@ __device__ inline bool rec_search(const RecCtx& x, LlrFn llr) {
         const int fb = p >> 3, c = fb / bpc;
         if (c < 4) rec_flip(x, c * 68 + fb % bpc, p & 7);
     };
-    for (int base = 0; base < data_bits; base += 64) {       // single data bit: accepted without re-verification
-        const int p = base + lane;
-        unsigned long long hits = __ballot(p < data_bits && delta(p) == syn && (p >> 3) / bpc < 4);
-        if (hits) { fix(base + __builtin_ctzll(hits)); return true; }
+    {   // single data bit: accepted without re-verification.  All table loads first, then the ordered test
+        constexpr int kMaxRounds = (4 * 68 * 8 + 63) / 64;
+        uint32_t dl[kMaxRounds];
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) { const int p = 64 * q + lane; dl[q] = (p < data_bits) ? delta(p) : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            const int base = 64 * q, p = base + lane;
+            if (base >= data_bits) break;
+            unsigned long long hits = __ballot(p < data_bits && dl[q] == syn && (p >> 3) / bpc < 4);
+            if (hits) { fix(base + __builtin_ctzll(hits)); return true; }
+        }
     }
     for (int bit = 0; bit < 16; ++bit)                        // a bit of the stored CRC itself
         if (syn == (1u << bit)) {
@@ -167,18 +293,29 @@ __device__ inline bool rec_search(const RecCtx& x, LlrFn llr) {
             if (c < 4) { rec_flip(x, c * 68 + fb % bpc, bit & 7); return true; }
         }
     // suspects: decoded bit (LSB-first index, as the reference reads it) differs from the channel's hard decision
+    stamp(1);
     int ns_all = 0;
     const int cw_bits = (bpc * 8 < 648) ? bpc * 8 : 648;
-    for (int c = 0; c < 4; ++c)
-        for (int base = 0; base < cw_bits; base += 64) {
+    for (int c = 0; c < 4; ++c) {
+        // the codeword's soft bits first, all loads in flight together (up to 9 per lane), then the ordered compaction
+        constexpr int kMaxRounds = 9;   // ceil(68 * 8 / 64)
+        float lv[kMaxRounds];
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            const int i = 64 * q + lane;
+            lv[q] = (i < cw_bits && ((c * bpc * 8 + i) >> 3) < data_bytes) ? llr(c, i) : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            const int base = 64 * q;
+            if (base >= cw_bits) break;
             const int i = base + lane;
             bool is = false;
-            float l = 0.0f;
+            const float l = lv[q];
             int fbit = 0;
             if (i < cw_bits) {
                 fbit = c * bpc * 8 + i;
                 if ((fbit >> 3) < data_bytes) {
-                    l = llr(c, i);
                     const int chb = (l < 0.0f) ? 1 : 0, db = (x.cw[c * 68 + (i >> 3)] >> (i & 7)) & 1;
                     is = chb != db;
                 }
@@ -186,17 +323,27 @@ __device__ inline bool rec_search(const RecCtx& x, LlrFn llr) {
             const unsigned long long mk = __ballot(is);
             if (is) {
                 const int at = ns_all + __popcll(mk & ((1ull << lane) - 1ull));
-                x.sus[at].frame_bit = fbit;
-                x.sus[at].abs_llr = fabs_(l);
+                if (at < x.sus_cap) {
+                    x.sus[at].frame_bit = fbit;
+                    x.sus[at].abs_llr = fabs_(l);
+                }
             }
             ns_all += __popcll(mk);
         }
+    }
+    if (ns_all > x.sus_cap) return kRecOverflow;
     wave_sync();
-    if (lane == 0) sort_exact_prefix(x.sus, ns_all, 30, x.stack, suspect_lt);
-    wave_sync();
+    stamp(2);
+    rec_sort_suspects_wave(x, ns_all, 30);
+    stamp(3);
+    if (x.dbg && lane == 0) x.dbg[7] = static_cast<unsigned long long>(ns_all);
     const int ns = ns_all < 30 ? ns_all : 30;
-    if (lane < ns) x.sd[lane] = static_cast<uint16_t>(delta(x.sus[lane].frame_bit));
-    wave_sync();
+    // CRC deltas of the (at most 30) suspects live in lane a of one register: the search loops below read them with
+    // v_readlane instead of going through LDS
+    const uint32_t my = (lane < ns) ? delta(x.sus[lane].frame_bit) : 0u;
+    auto sd_at = [&](int a) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(my), a)); };   // uniform a
+    auto sd_lane = [&](int a) -> uint32_t { return static_cast<uint32_t>(__shfl(static_cast<int>(my), a)); };                          // per-lane a
+    auto sd_at_lane = [&](uint32_t mine, int p, int ln) -> uint32_t { (void)p; (void)ln; return mine; };                                // lane p's own delta
     auto attempt = [&](int n_idx, int a, int b, int c, int d) -> bool {
         const int idx[4] = {a, b, c, d};
         for (int q = 0; q < n_idx; ++q) fix(x.sus[idx[q]].frame_bit);
@@ -204,37 +351,69 @@ __device__ inline bool rec_search(const RecCtx& x, LlrFn llr) {
         for (int q = 0; q < n_idx; ++q) fix(x.sus[idx[q]].frame_bit);
         return false;
     };
-    const uint32_t my = (lane < ns) ? x.sd[lane] : 0u;
-    for (int a = 0; a < ns; ++a) {                            // pairs
-        unsigned long long hits = __ballot(lane > a && lane < ns && (x.sd[a] ^ my) == syn);
-        while (hits) {
-            const int b = __builtin_ctzll(hits);
-            hits &= hits - 1;
-            if (attempt(2, a, b, 0, 0)) return true;
-        }
-    }
-    for (int a = 0; a < ns; ++a)                              // triples
-        for (int b = a + 1; b < ns; ++b) {
-            const uint32_t ab = static_cast<uint32_t>(x.sd[a] ^ x.sd[b]);
-            unsigned long long hits = __ballot(lane > b && lane < ns && (ab ^ my) == syn);
-            while (hits) {
-                const int c = __builtin_ctzll(hits);
-                hits &= hits - 1;
-                if (attempt(3, a, b, c, 0)) return true;
+    // The reference walks pairs, then triples, then quadruples of suspects in lexicographic order and tries every
+    // combination whose CRC deltas xor to the syndrome, first success wins.  Per class, one lane per PREFIX (the
+    // combination without its last member, enumerated in lexicographic order) looks for the smallest last member that
+    // completes it; hits are rare (2^-16 per combination), so the common case is a handful of select instructions
+    // per prefix and no ballot at all.  Hits are then tried in the reference's order.
+    auto try_class = [&](int n_idx, int n_members, int n_prefixes, auto prefix_of) -> bool {
+        for (int base = 0; base < n_prefixes; base += 64) {
+            const bool valid = base + lane < n_prefixes;
+            const int p = valid ? base + lane : n_prefixes - 1;   // every lane decodes a prefix: the shuffles inside need all lanes active
+            int ia = 0, ib = 0, ic = 0;
+            uint32_t want = 0u;
+            int last_from = n_members;
+            prefix_of(p, ia, ib, ic, want, last_from);
+            // every completion of this lane's prefix, ascending: a bit mask of the members d >= last_from with delta == want
+            uint32_t found = 0u;
+            for (int d = 1; d < n_members; ++d) {
+                const uint32_t sdv = sd_at(d);
+                if (valid && d >= last_from && sdv == want) found |= 1u << d;
             }
-        }
-    const int n4 = ns < 15 ? ns : 15;
-    for (int a = 0; a < n4; ++a)                              // quadruples of the first 15
-        for (int b = a + 1; b < n4; ++b)
-            for (int c = b + 1; c < n4; ++c) {
-                const uint32_t abc = static_cast<uint32_t>(x.sd[a] ^ x.sd[b] ^ x.sd[c]);
-                unsigned long long hits = __ballot(lane > c && lane < n4 && (abc ^ my) == syn);
-                while (hits) {
-                    const int d = __builtin_ctzll(hits);
-                    hits &= hits - 1;
-                    if (attempt(4, a, b, c, d)) return true;
+            unsigned long long lanes = __ballot(found != 0u);
+            while (lanes) {                                   // prefixes in lexicographic order
+                const int l = __builtin_ctzll(lanes);
+                lanes &= lanes - 1;
+                uint32_t f = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(found), l));
+                const int pa = __builtin_amdgcn_readlane(ia, l), pb = __builtin_amdgcn_readlane(ib, l), pc = __builtin_amdgcn_readlane(ic, l);
+                while (f) {                                   // completions in ascending order
+                    const int d = __builtin_ctz(f);
+                    f &= f - 1;
+                    const bool ok = (n_idx == 2) ? attempt(2, pa, d, 0, 0) : (n_idx == 3) ? attempt(3, pa, pb, d, 0) : attempt(4, pa, pb, pc, d);
+                    if (ok) return true;
                 }
             }
+        }
+        return false;
+    };
+    // pairs (a, b): prefix = a
+    if (try_class(2, ns, ns, [&](int p, int& ia, int& ib, int& ic, uint32_t& want, int& from) {
+            (void)ib; (void)ic; ia = p; want = syn ^ sd_at_lane(my, p, lane); from = p + 1; })) return true;
+    stamp(4);
+    // triples (a, b, c): prefix = (a, b), a < b, lexicographic
+    {
+        const int np = ns * (ns - 1) / 2;
+        if (try_class(3, ns, np, [&](int p, int& ia, int& ib, int& ic, uint32_t& want, int& from) {
+                (void)ic;
+                int a = 0, rem = p;                           // p -> (a, b): row a holds ns - 1 - a pairs
+                while (rem >= ns - 1 - a) { rem -= ns - 1 - a; ++a; }
+                ia = a; ib = a + 1 + rem;
+                want = syn ^ sd_lane(ia) ^ sd_lane(ib); from = ib + 1; })) return true;
+    }
+    stamp(5);
+    // quadruples of the first 15 (a, b, c, d): prefix = (a, b, c)
+    {
+        const int n4 = ns < 15 ? ns : 15;
+        const int np = n4 * (n4 - 1) * (n4 - 2) / 6;
+        if (try_class(4, n4, np, [&](int p, int& ia, int& ib, int& ic, uint32_t& want, int& from) {
+                int a = 0, rem = p;                           // p -> (a, b, c), lexicographic
+                for (;;) { const int m = n4 - 1 - a, cnt = m * (m - 1) / 2; if (rem < cnt) break; rem -= cnt; ++a; }
+                int b = a + 1;
+                for (;;) { const int cnt = n4 - 1 - b; if (rem < cnt) break; rem -= cnt; ++b; }
+                ia = a; ib = b; ic = b + 1 + rem;
+                want = syn ^ sd_lane(ia) ^ sd_lane(ib) ^ sd_lane(ic); from = ic + 1; })) return true;
+    }
+    stamp(6);
     return false;
 }
 
@@ -247,6 +426,9 @@ struct RecoveryArgs {
     unsigned int* n_stage2;      // counter
     unsigned int* stage2;        // [n_frames] frames whose stage 1 failed
     unsigned int* next_fill;     // counter: work queue head of recovery_fill_kernel
+    unsigned long long* dbg;     // nullable: [n_frames][8] stage-1 cycle stamps (RIA_DEBUG_REC_STAMPS)
+    unsigned int* n_overflow;    // counter
+    unsigned int* overflow;      // [n_frames] frames with more suspects than the small stage-1 instance holds
     int list_units_now;          // recovery_list_kernel also lists the missing re-decodes (host-search path)
     // host-search staging (RIA_RECOVERY_HOST=1 only)
     uint8_t* info_c;             // [n_flagged][4*bpc]
@@ -305,16 +487,25 @@ __global__ __launch_bounds__(256) void recovery_gather_kernel(RecoveryArgs R) {
 }
 
 
-__host__ __device__ inline int recovery_lds_bytes(int bpc) { return 1024 + 4 * bpc * 8 * 8 + 192 * 4 + 64; }
+// LDS of one frame's wave: codewords / frame / trial / deltas (1 KB), sort stack, suspects.  BIG: room for every bit of
+// the frame (4 * bpc * 8 suspects); the common instance holds kRecSmallCap of them
+__host__ __device__ inline int recovery_sus_cap(int bpc, bool big) { return big ? 4 * bpc * 8 : (kRecSmallCap < 4 * bpc * 8 ? kRecSmallCap : 4 * bpc * 8); }
+__host__ __device__ inline int recovery_lds_bytes(int bpc, bool big = true) {
+    const int cap = recovery_sus_cap(bpc, big);
+    return 1024 + cap * 8 + 192 * 4 + 2 * (cap / 2 + 32) * 2 + 64;
+}
 
 // ---- device path: stage 1 for every flagged frame; the frames it cannot recover queue the re-decodes the
 // fallback needs; stage 2 runs for those only, after recovery_fill_kernel
-__device__ inline void rec_setup(RecCtx& x, unsigned char* smem, const RecoveryArgs& R, int lane) {
+__device__ inline void rec_setup(RecCtx& x, unsigned char* smem, const RecoveryArgs& R, int lane, bool big = true) {
+    x.sus_cap = recovery_sus_cap(R.d.c.bytes_per_cw, big);
     x.cw = smem; x.fd = smem + 272; x.trial = smem + 544;
     x.sd = reinterpret_cast<uint16_t*>(smem + 816);
     x.stack = reinterpret_cast<int*>(smem + 1024);
     x.sus = reinterpret_cast<Suspect*>(smem + 1024 + 192 * 4);
+    x.lists = reinterpret_cast<uint16_t*>(smem + 1024 + 192 * 4 + x.sus_cap * 8);
     x.bpc = R.d.c.bytes_per_cw; x.crc_bit = R.d.crc_bit; x.crc_init = R.d.crc_init; x.lane = lane;
+    x.dbg = nullptr;
 }
 __device__ inline void rec_load_cw(const RecCtx& x, const uint8_t* info, int lane) {
     for (int i = lane; i < 4 * 68; i += 64) { const int c = i / 68, b = i - c * 68; x.cw[i] = (b < x.bpc) ? info[c * x.bpc + b] : 0; }
@@ -331,6 +522,9 @@ __device__ inline void rec_publish(const RecCtx& x, const RecoveryArgs& R, unsig
     }
 }
 
+// The reference compares the decoded bits read LSB-first with the hard decisions of MSB-first soft bits
+// (frame_v2.cpp:1700-1716), so about HALF of a frame's bits are "suspects" (640 of 1280 on the bench workload): the
+// suspect array always needs room for every bit.
 __global__ __launch_bounds__(64) void recovery_stage1_kernel(RecoveryArgs R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned q = blockIdx.x;
@@ -338,12 +532,14 @@ __global__ __launch_bounds__(64) void recovery_stage1_kernel(RecoveryArgs R) {
     const unsigned frame = R.flagged[q];
     const int lane = threadIdx.x;
     RecCtx x;
-    rec_setup(x, smem, R, lane);
+    rec_setup(x, smem, R, lane, true);
+    if (R.dbg) x.dbg = R.dbg + static_cast<size_t>(frame) * 8;
     uint8_t* info = R.d.info_out + static_cast<size_t>(frame) * 4 * x.bpc;
     rec_load_cw(x, info, lane);
     const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
     const uint16_t* gather = R.d.gather;
-    const bool good = rec_search(x, [&](int c, int i) { return fl[gather[c * 648 + i]]; });
+    const int good = rec_search(x, [&](int c, int i) { return fl[gather[c * 648 + i]]; });
+    if (good == kRecOverflow) return;   // cannot happen: the array holds every bit of the frame
     if (good) { rec_publish(x, R, frame, info, true, lane); return; }
     if (lane == 0) {
         R.stage2[atomicAdd(R.n_stage2, 1u)] = frame;

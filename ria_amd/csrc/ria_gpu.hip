@@ -82,7 +82,7 @@ struct ria_gpu {
     unsigned char* d_hstage = nullptr; unsigned char* p_hstage = nullptr; size_t hstage_bytes = 0; hipStream_t hstream = nullptr;
     int zc_lds_opted = 0, mc_lds_opted = 0, lts_lds_opted = 0;   // dynamic-LDS opt-ins made on this handle's device
     // CRC-recovery staging (device + pinned host mirrors), sized for ws_frames
-    unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr; unsigned int* d_stage2 = nullptr;
+    unsigned int* d_rctl = nullptr; unsigned int* d_flagged = nullptr; unsigned int* d_list2 = nullptr; unsigned int* d_stage2 = nullptr; unsigned int* d_overflow = nullptr;
     uint8_t* d_info_c = nullptr; float* d_rows_c = nullptr; uint8_t* d_redec_ok = nullptr; uint8_t* d_redec_bytes = nullptr;
     ria_decode_status* d_st_c = nullptr;
     unsigned int* p_rctl = nullptr; unsigned int* p_flagged = nullptr; uint8_t* p_info_c = nullptr; float* p_rows_c = nullptr;
@@ -205,8 +205,10 @@ static hipError_t ensure_recovery_ws(ria_gpu_handle h, int n_frames, bool host_s
     hipError_t e;
 #define A_TRY(expr) if ((e = (expr)) != hipSuccess) return e
     if (n_frames > h->rec_frames) {
-        for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_stage2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 16 * kMaxParts));   // one 16-byte counter block per stream slot
+        for (void** p : {(void**)&h->d_rctl, (void**)&h->d_flagged, (void**)&h->d_list2, (void**)&h->d_stage2, (void**)&h->d_overflow}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        h->rec_frames = 0;
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_rctl), 32 * kMaxParts));   // one 32-byte counter block per stream slot
+        A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_overflow), n * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_flagged), n * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_list2), n * 16 * 4));
         A_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_stage2), n * 4));
@@ -266,11 +268,13 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
     if (e0 != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery workspace: %s", hipGetErrorString(e0));
     RecoveryArgs R{};
     R.d = D;
-    unsigned int* rctl = h->d_rctl + 4 * slot;
-    R.n_flagged = rctl; R.n_list2 = rctl + 1; R.n_stage2 = rctl + 2; R.next_fill = rctl + 3;
+    unsigned int* rctl = h->d_rctl + 8 * slot;
+    R.n_flagged = rctl; R.n_list2 = rctl + 1; R.n_stage2 = rctl + 2; R.next_fill = rctl + 3; R.n_overflow = rctl + 4;
     R.flagged = h->d_flagged + ws_off; R.list2 = h->d_list2 + static_cast<size_t>(ws_off) * 16; R.stage2 = h->d_stage2 + ws_off;
+    R.overflow = h->d_overflow + ws_off;
+    if (const char* e = getenv("RIA_DEBUG_REC_STAMPS")) R.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
     R.list_units_now = 0;
-    if (hipMemsetAsync(rctl, 0, 16, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
+    if (hipMemsetAsync(rctl, 0, 32, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
     const int rl = recovery_lds_bytes(h->geo.bytes_per_codeword);
     hipLaunchKernelGGL(recovery_list_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, R);
     hipLaunchKernelGGL(recovery_stage1_kernel, dim3(n_frames), dim3(64), rl, s, R);
@@ -400,7 +404,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
     for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
-                    (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c}) if (p) (void)hipFree(p);
+                    (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c, (void*)h->d_overflow}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
                     (void*)h->p_redec_bytes, (void*)h->p_st_c}) if (p) (void)hipHostFree(p);
     delete h;

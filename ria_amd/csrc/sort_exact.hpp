@@ -151,4 +151,61 @@ RIA_SORT_HD inline void sort_exact_prefix(T* v, int n, int want, int* stack, C l
     }
 }
 
+// ---- the same result computed in a data-parallel way ------------------------------------------------------------
+// __unguarded_partition is a two-pointer loop, but what it does is fixed by two lists: A = the positions in
+// (first, last) whose key is NOT below the pivot, ascending, and B = the positions whose key is NOT above it, descending.
+// Swap k of the loop exchanges A[k] and B[k]; the loop stops at the first k with A[k] >= B[k] and returns
+// min(A[k], B[k-1]) (the left scan stops on the element the previous swap parked on the right, the right scan on the
+// one it parked on the left).  Counting and list building are prefix sums: on the GPU a wave does a whole pass with
+// ballots (recovery_kernels.hip.h); this host form states the rule and is checked against std::sort.
+// After the partitions, __final_insertion_sort is a stable sort (strict comparator, elements only pass strictly
+// greater ones) of the first min(n, want + 16) positions: a rank computation.
+template <class T, class C>
+RIA_SORT_HD inline int partition_lists(T* v, int first, int last, C lt, int* alist, int* blist) {
+    T *f = v + first, *mid = v + first + (last - first) / 2, *a = v + first + 1, *b = mid, *c = v + last - 1;
+    if (lt(*a, *b)) {
+        if (lt(*b, *c)) sortx::swp(*f, *b); else if (lt(*a, *c)) sortx::swp(*f, *c); else sortx::swp(*f, *a);
+    } else {
+        if (lt(*a, *c)) sortx::swp(*f, *a); else if (lt(*b, *c)) sortx::swp(*f, *c); else sortx::swp(*f, *b);
+    }
+    const T pivot = *f;
+    int na = 0, nb = 0;
+    for (int i = first + 1; i < last; ++i) if (!lt(v[i], pivot)) alist[na++] = i;
+    for (int i = last - 1; i > first; --i) if (!lt(pivot, v[i])) blist[nb++] = i;
+    int k = 0;
+    while (k < na && k < nb && alist[k] < blist[k]) ++k;
+    for (int q = 0; q < k; ++q) sortx::swp(v[alist[q]], v[blist[q]]);
+    const int big = 0x7fffffff;
+    const int ca = (k < na) ? alist[k] : big, cb = (k > 0) ? blist[k - 1] : big;
+    return ca < cb ? ca : cb;
+}
+template <class T, class C>
+RIA_SORT_HD inline void sort_exact_prefix_lists(T* v, int n, int want, int* stack, C lt, int* alist, int* blist, T* tmp) {
+    if (n <= 0) return;
+    const int limit = (want >= n) ? n : want + 16;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    int sp = 1;
+    stack[0] = 0; stack[1] = n; stack[2] = 2 * lg;
+    while (sp > 0) {
+        --sp;
+        int first = stack[3 * sp], last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        while (last - first > 16) {
+            if (first >= limit) break;
+            if (depth == 0) { sortx::heap_sort(v + first, v + last, lt); break; }
+            --depth;
+            const int cut = partition_lists(v, first, last, lt, alist, blist);
+            if (cut < limit) { stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; ++sp; }
+            last = cut;
+        }
+    }
+    const int fin = (limit < n) ? limit : n;
+    for (int i = 0; i < fin; ++i) {          // stable rank sort of the first `fin` positions
+        int rank = 0;
+        for (int j = 0; j < fin; ++j) rank += (lt(v[j], v[i]) || (j < i && !lt(v[i], v[j]))) ? 1 : 0;
+        tmp[rank] = v[i];
+    }
+    for (int i = 0; i < fin; ++i) v[i] = tmp[i];
+}
+
 }  // namespace ria

@@ -24,6 +24,15 @@ int main() {
         ria::sort_exact_prefix(part.data(), n, 30, stack, ria::suspect_lt);
         for (int i = 0; i < n; ++i) if (full[i].frame_bit != ref[i].frame_bit) { ++bad; break; }
         for (int i = 0; i < std::min(n, 30); ++i) if (part[i].frame_bit != ref[i].frame_bit) { ++bad; break; }
+        {   // the data-parallel formulation (what the GPU wave runs): same prefix
+            std::vector<ria::Suspect> lp = a, tmp(n + 64);
+            std::vector<int> al(n + 1), bl(n + 1);
+            ria::sort_exact_prefix_lists(lp.data(), n, 30, stack, ria::suspect_lt, al.data(), bl.data(), tmp.data());
+            for (int i = 0; i < std::min(n, 30); ++i) if (lp[i].frame_bit != ref[i].frame_bit) { ++bad; break; }
+            std::vector<ria::Suspect> lf = a;
+            ria::sort_exact_prefix_lists(lf.data(), n, n, stack, ria::suspect_lt, al.data(), bl.data(), tmp.data());
+            for (int i = 0; i < n; ++i) if (lf[i].frame_bit != ref[i].frame_bit) { ++bad; break; }
+        }
         // forced depth budget 0: the library's fallback is __partial_sort(first, last, last)
         if (n > 16) {
             std::partial_sort(heap.begin(), heap.end(), heap.end(), ria::suspect_lt);
