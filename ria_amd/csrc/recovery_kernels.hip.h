@@ -230,34 +230,83 @@ __device__ inline int rec_search(const RecCtx& x, LlrFn llr) {
             if (by == 1) return 1u << bit;
             return 0u;
         };
-        for (int base = 0; base < tb; base += 64) {          // single bit, ascending bit index
-            const int b = base + lane;
-            unsigned long long hits = __ballot(b < tb && (hsyn ^ dh(b)) == 0u && (msyn ^ dm(b)) == 0u);
-            while (hits) {
-                const int bb = base + __builtin_ctzll(hits);
-                hits &= hits - 1;
-                rec_flip(x, bb >> 3, bb & 7);
-                if (rec_try(x)) return true;
-                rec_flip(x, bb >> 3, bb & 7);
-            }
-        }
-        for (int b1 = 0; b1 < tb; ++b1) {                    // pairs b1 < b2, b2 ascending inside b1
-            const uint32_t h1 = hsyn ^ dh(b1), m1 = msyn ^ dm(b1);
-            // only bits of the first 17 bytes move either syndrome: beyond them a second bit can cancel
-            // nothing, so a hit there needs h1 == 0 && m1 == 0 already
-            for (int base = b1 + 1; base < tb; base += 64) {
-                const int b2 = base + lane;
-                unsigned long long hits = __ballot(b2 < tb && (h1 ^ dh(b2)) == 0u && (m1 ^ dm(b2)) == 0u);
+        // Both syndromes of a flipped bit b packed in one word, D(b) = dh(b) << 16 | dm(b): nonzero only inside the
+        // first 17 bytes, and the same for every frame.  Lane l keeps D(l), D(l + 64), D(l + 128) in registers (bits
+        // 136.. have D = 0), so the searches below are register compares: no table load inside the loops.
+        const uint32_t d0 = (dh(lane) << 16) | dm(lane), d1 = (dh(lane + 64) << 16) | dm(lane + 64), d2 = (dh(lane + 128) << 16) | dm(lane + 128);
+        const uint32_t syn2 = (hsyn << 16) | msyn;
+        auto d_of = [&](int b) -> uint32_t {                 // uniform b
+            if (b >= 192) return 0u;
+            const uint32_t r = (b < 64) ? d0 : (b < 128) ? d1 : d2;
+            return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(r), b & 63));
+        };
+        // candidates b2 in [from, tb) with D(b2) == want, ascending: f(b2) is called for each until it returns true
+        auto for_matches = [&](uint32_t want, int from, auto f) -> bool {
+            for (int base = 0; base < 192 && base < tb; base += 64) {
+                const int b = base + lane;
+                const uint32_t dv = (base == 0) ? d0 : (base == 64) ? d1 : d2;
+                unsigned long long hits = __ballot(b >= from && b < tb && dv == want);
                 while (hits) {
                     const int bb = base + __builtin_ctzll(hits);
                     hits &= hits - 1;
+                    if (f(bb)) return true;
+                }
+            }
+            if (want == 0u)                                   // bits beyond the first 24 bytes move neither syndrome
+                for (int bb = (from > 192 ? from : 192); bb < tb; ++bb) if (f(bb)) return true;
+            return false;
+        };
+        if (for_matches(syn2, 0, [&](int bb) {               // single bit, ascending bit index
+                rec_flip(x, bb >> 3, bb & 7);
+                if (rec_try(x)) return true;
+                rec_flip(x, bb >> 3, bb & 7);
+                return false; })) return true;
+        for (int b1 = 0; b1 < tb; ++b1) {                    // pairs b1 < b2, b2 ascending inside b1
+            const uint32_t want = syn2 ^ d_of(b1);
+            if (want == 0u) {
+                // Flipping b1 alone repairs the header (and did not verify above), so EVERY b2 outside the first 17
+                // bytes passes the header filter: the reference tries them all, 184 full verifications.  With the header
+                // fixed the verdict on (b1, b2) is the frame CRC alone, which is linear in b2 as well: one evaluation
+                // of the syndrome after b1, then only the b2 whose delta cancels it are really tried (in order).
+                rec_flip(x, b1 >> 3, b1 & 7);
+                const int tl = rec_reassemble(x, x.trial);
+                bool ctl2 = false; int plen2 = 0;
+                const bool hdr = tl > 0 && rec_parse_header(x, x.trial, tl, &ctl2, &plen2);
+                const int exp2 = 17 + plen2 + 2;
+                bool done = false;
+                if (hdr && !ctl2 && tl >= exp2) {
+                    const uint32_t s2 = static_cast<uint32_t>((x.trial[exp2 - 2] << 8) | x.trial[exp2 - 1]) ^
+                                        crc16_wave(x.trial, exp2 - 2, x.crc_bit, x.crc_init, lane);
+                    const int from = (b1 + 1 > 136) ? b1 + 1 : 136;
+                    for (int base = (from & ~63); base < tb && !done; base += 64) {
+                        const int b2 = base + lane, by = b2 >> 3, bit = b2 & 7;
+                        uint32_t dl = 0u;                      // change of the frame-CRC syndrome when bit b2 of codeword 0 flips
+                        if (b2 < tb) {
+                            if (by < exp2 - 2) dl = x.crc_bit[(exp2 - 3 - by) * 8 + bit];
+                            else if (by < exp2) dl = 1u << (bit + 8 * (exp2 - 1 - by));
+                        }
+                        unsigned long long hits = __ballot(b2 >= from && b2 < tb && dl == s2);
+                        while (hits && !done) {
+                            const int bb = base + __builtin_ctzll(hits);
+                            hits &= hits - 1;
+                            rec_flip(x, bb >> 3, bb & 7);
+                            if (rec_try(x)) done = true; else rec_flip(x, bb >> 3, bb & 7);
+                        }
+                    }
+                } else if (hdr && ctl2) {
+                    done = true;                              // a control frame verifies on its header alone (not reachable: the single-bit pass would have taken it)
+                }
+                if (done) return true;
+                rec_flip(x, b1 >> 3, b1 & 7);
+                continue;
+            }
+            if (for_matches(want, b1 + 1, [&](int bb) {
                     rec_flip(x, b1 >> 3, b1 & 7);
                     rec_flip(x, bb >> 3, bb & 7);
                     if (rec_try(x)) return true;
                     rec_flip(x, bb >> 3, bb & 7);
                     rec_flip(x, b1 >> 3, b1 & 7);
-                }
-            }
+                    return false; })) return true;
         }
         return false;
     }
@@ -400,7 +449,6 @@ __device__ inline int rec_search(const RecCtx& x, LlrFn llr) {
                 ia = a; ib = a + 1 + rem;
                 want = syn ^ sd_lane(ia) ^ sd_lane(ib); from = ib + 1; })) return true;
     }
-    stamp(5);
     // quadruples of the first 15 (a, b, c, d): prefix = (a, b, c)
     {
         const int n4 = ns < 15 ? ns : 15;
@@ -413,7 +461,6 @@ __device__ inline int rec_search(const RecCtx& x, LlrFn llr) {
                 ia = a; ib = b; ic = b + 1 + rem;
                 want = syn ^ sd_lane(ia) ^ sd_lane(ib) ^ sd_lane(ic); from = ic + 1; })) return true;
     }
-    stamp(6);
     return false;
 }
 
@@ -539,16 +586,22 @@ __global__ __launch_bounds__(64) void recovery_stage1_kernel(RecoveryArgs R) {
     const float* fl = R.d.llr + static_cast<size_t>(frame) * R.d.llr_stride;
     const uint16_t* gather = R.d.gather;
     const int good = rec_search(x, [&](int c, int i) { return fl[gather[c * 648 + i]]; });
+    if (x.dbg && lane == 0) { x.dbg[6] = __builtin_readcyclecounter(); x.dbg[5] = static_cast<unsigned long long>(good); }
     if (good == kRecOverflow) return;   // cannot happen: the array holds every bit of the frame
     if (good) { rec_publish(x, R, frame, info, true, lane); return; }
+    // queue the (codeword, factor) decodes the fallback still misses: lanes 0..15 = (codeword, factor) pairs, ONE
+    // reservation per frame on the shared counter (a counter bumped once per entry by thousands of waves serialises)
+    const unsigned fc = frame * 4u + static_cast<unsigned>(lane >> 2);
+    const int f = 1 + (lane & 3);
+    const bool need = lane < 16 && R.d.res[fc].state[f] == 0;
+    const unsigned long long mk = __ballot(need);
+    unsigned base = 0;
     if (lane == 0) {
         R.stage2[atomicAdd(R.n_stage2, 1u)] = frame;
-        for (int cw = 0; cw < 4; ++cw) {
-            const unsigned fc = frame * 4u + cw;
-            for (int f = 1; f <= 4; ++f)
-                if (R.d.res[fc].state[f] == 0) R.list2[atomicAdd(R.n_list2, 1u)] = (fc << 3) | static_cast<unsigned>(f);
-        }
+        if (mk) base = atomicAdd(R.n_list2, static_cast<unsigned>(__popcll(mk)));
     }
+    base = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+    if (need) R.list2[base + __popcll(mk & ((1ull << lane) - 1ull))] = (fc << 3) | static_cast<unsigned>(f);
 }
 
 // Stage 2 (frame_v2.cpp:1836-1866): factors 0.75, 0.625, 0.5, 0.875 = kFactors[2, 3, 4, 1]; stage 1 left the

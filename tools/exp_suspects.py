@@ -27,9 +27,8 @@ os.environ["RIA_NO_SPLIT"] = "1"
 d2, st2 = e.decode(llr, flags=capi.DECODE_FULL)
 torch.cuda.synchronize()
 t = stt.cpu().numpy()[fl].astype(np.float64)
-full = t[:, 6] > 0     # frames that ran the whole search without success
-for name, m in (("searched to the end", full), ("ended early (recovered / overflow path)", ~full)):
-    if m.sum() == 0: continue
-    q = t[m]
-    print(name, int(m.sum()), "cycles: reassemble+single %.0f  suspects %.0f  sort %.0f  pairs %.0f  triples %.0f  quads %.0f  | ns_all mean %.0f" % (
-        (q[:, 1] - q[:, 0]).mean(), (q[:, 2] - q[:, 1]).mean(), (q[:, 3] - q[:, 2]).mean(), (q[:, 4] - q[:, 3]).mean(), (q[:, 5] - q[:, 4]).mean(), (q[:, 6] - q[:, 5]).mean(), q[:, 7].mean()))
+tot = t[:, 6] - t[:, 0]
+hdr = t[:, 1] == 0            # never reached the suspect stage: header case or early single-bit success
+print("per-frame total cycles: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max()))
+for name, m in (("reached suspects", ~hdr), ("did not", hdr)):
+    if m.sum(): print(name, int(m.sum()), "mean %.0f p99 %.0f max %.0f" % (tot[m].mean(), np.percentile(tot[m], 99), tot[m].max()), "recovered", int((t[m, 5] == 1).sum()))
