@@ -378,6 +378,10 @@ int ria_gpu_burst_interleave_batch(ria_gpu_handle h, const uint8_t* logical_byte
  * math the kernels use on n arguments (tests compare against the host libm). */
 int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n,
                        float* out_dev, void* stream);
+/* 1 if, in the handle's last decode calls, a persistent work-queue wave left its loop through the iteration bound
+ * instead of the queue's end (a broken queue loop terminates and is reported, it does not hang the GPU); 0 if not;
+ * negative = error.  Synchronises the device. */
+int ria_gpu_debug_queue_fault(ria_gpu_handle h);
 
 #ifdef __cplusplus
 }

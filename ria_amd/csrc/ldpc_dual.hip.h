@@ -251,9 +251,11 @@ struct Phase0Ops {
     unsigned total;
     unsigned fc[2];
     int fi[2];
+    unsigned guard = 0;
     template <int C>
     __device__ bool fetch(DualState<S>& st, float* factor, int* max_iter) {
-        unsigned u = atomicAdd(&A.ctl->next_z, lane == 0 ? 1u : 0u);   // all-lane atomic form (see fast_phase0_kernel)
+        if (++guard > total + 2u) { if (lane == 0) atomicExch(&A.ctl->queue_fault, 1u); return false; }   // RIA_QUEUE_GUARD
+        unsigned u = atomicAdd(&A.ctl->next_z, lane == 0 ? 1u : 0u);   // all-lane atomic form
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= total) return false;
         fc[C] = A.list1[u >> 2];
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (2u * blockIdx.x >= total) return;
     DualState<S> st;
     dual_load_tables(st, A.c, smem, lane);
-    Phase0Ops<S> ops{A, smem, lane, total, {0u, 0u}, {0, 0}};
+    Phase0Ops<S> ops{A, smem, lane, total, {0u, 0u}, {0, 0}, 0u};
     dual_decode_loop<S>(st, A.c, smem, lane, ops);
 }
 
@@ -291,10 +293,12 @@ struct CascadeOps {
     int lane;
     unsigned n_entries, total;
     unsigned e[2], a[2];
+    unsigned guard = 0;
     template <int C>
     __device__ bool fetch(DualState<S>& st, float* factor, int* max_iter) {
         const FastCode& c = A.c;
         for (;;) {
+            if (++guard > total + 2u) { if (lane == 0) atomicExch(&A.ctl->queue_fault, 1u); return false; }   // RIA_QUEUE_GUARD
             unsigned u = atomicAdd(&A.ctl->next_unit, lane == 0 ? 1u : 0u);
             u = __builtin_amdgcn_readfirstlane(u);
             if (u >= total) return false;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (total == 0) return;
     DualState<S> st;
     dual_load_tables(st, A.c, smem, lane);
-    CascadeOps<S> ops{A, smem, lane, n_entries, total, {0u, 0u}, {0u, 0u}};
+    CascadeOps<S> ops{A, smem, lane, n_entries, total, {0u, 0u}, {0u, 0u}, 0u};
     dual_decode_loop<S>(st, A.c, smem, lane, ops);
 }
 

@@ -448,7 +448,16 @@ struct DecodeCtl {          // zeroed by hipMemsetAsync before every decode call
     unsigned int next_unit; // cascade work queue head
     unsigned int n_list1;   // codewords that need the other four min-sum factors
     unsigned int next_z;    // phase-0 work queue head
+    unsigned int queue_fault;  // set by a persistent wave whose queue loop ran past its bound (see kQueueGuard)
+    unsigned int pad_[3];
 };
+// Every persistent work-queue loop is bounded: a wave can pop at most `total` live units plus one terminating index,
+// so a loop that has gone round more often than that is broken (in round 1 a lane-0-only form of the queue pop looped
+// on unit 0 for ever; the cause was not isolated).  The pops are written in the all-lane form (lane 0 adds 1, the
+// others 0, readfirstlane), which has no divergent branch, and a loop that still exceeds its bound records it in
+// DecodeCtl::queue_fault and leaves instead of hanging the GPU.
+#define RIA_QUEUE_GUARD(guard, total, ctl) \
+    if (++(guard) > (total) + 2u) { if (threadIdx.x == 0) atomicExch(&(ctl)->queue_fault, 1u); break; }
 
 // result of decoding one codeword's UNMODIFIED LLRs with factor kFactors[f]
 constexpr int kNumFactors = 5;
@@ -624,9 +633,9 @@ __global__ __launch_bounds__(64) void fast_phase0_kernel(FastDecodeArgs A) {
     if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
-    for (;;) {   // persistent waves over an atomic queue (ctl->next_z).  Every lane takes part in the atomic (lane 0
-                 // adds 1, the others 0): a lane-0-only atomic inside this loop is compiled into a loop nest that
-                 // never leaves unit 0 (hipcc 7.2, control-flow structurizer); this form has no divergent branch
+    unsigned guard = 0;
+    for (;;) {   // persistent waves over an atomic queue (ctl->next_z), all-lane pop (see RIA_QUEUE_GUARD)
+        RIA_QUEUE_GUARD(guard, total, A.ctl)
         unsigned u = atomicAdd(&A.ctl->next_z, lane == 0 ? 1u : 0u);
         u = __builtin_amdgcn_readfirstlane(u);   // scalar: the loop control and every address derived from u stay uniform
         if (u >= total) break;
@@ -718,8 +727,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
     if (total == 0) return;
     FastState<S> st;
     fast_load_tables(st, c, smem, lane);
+    unsigned guard = 0;
     for (;;) {
-        unsigned int u = atomicAdd(&A.ctl->next_unit, lane == 0 ? 1u : 0u);   // all lanes take part: see fast_phase0_kernel
+        RIA_QUEUE_GUARD(guard, total, A.ctl)
+        unsigned int u = atomicAdd(&A.ctl->next_unit, lane == 0 ? 1u : 0u);   // all lanes take part: see RIA_QUEUE_GUARD
         u = __builtin_amdgcn_readfirstlane(u);   // scalar: the loop control and every address derived from u stay uniform
         if (u >= total) break;
         const unsigned int a = u / n_entries, e = u - a * n_entries;
@@ -739,12 +750,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
         bool ok;
         const int it = fast_decode<S, S::kCascadeCv>(st, c, smem, factor, c.max_iter, lane, &ok);
         if (ok) {
-            unsigned int prev = 0;
-            if (lane == 0) prev = atomicMin(&A.best[e], a);
+            // all-lane forms here too (no lane-0-only atomic inside the loop): only lane 0's operand can change the word
+            unsigned int prev = atomicMin(&A.best[e], lane == 0 ? a : 0xFFFFFFFFu);
             prev = __builtin_amdgcn_readfirstlane(prev);
             if (a < prev) {   // best so far: publish under the entry's lock (held for one 40..68-byte store)
                 CascadeWin* w = A.win + e;
-                if (lane == 0) while (atomicCAS(&w->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                for (unsigned spin = 0;; ++spin) {   // wave-uniform spin: lane 0's compare-and-swap decides
+                    unsigned got = atomicCAS(&w->lock, 0u, lane == 0 ? 1u : 0u);
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    if (got == 0u) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
                 __threadfence();
                 unsigned int cur = __hip_atomic_load(&A.best[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cur = __builtin_amdgcn_readfirstlane(cur);

@@ -469,7 +469,7 @@ struct RecoveryArgs {
     unsigned int* n_flagged;     // counter
     unsigned int* flagged;       // [n_frames] frame indices needing recovery
     unsigned int* n_list2;       // counter
-    unsigned int* list2;         // [16*n_frames] (fc << 3) | factor index
+    unsigned int* list2;         // [4*n_frames used of 16*n_frames] (fc << 4) | mask of the factor indices 1..4 still to decode (bit f-1)
     unsigned int* n_stage2;      // counter
     unsigned int* stage2;        // [n_frames] frames whose stage 1 failed
     unsigned int* next_fill;     // counter: work queue head of recovery_fill_kernel
@@ -492,9 +492,10 @@ __global__ void recovery_list_kernel(RecoveryArgs R) {
     R.flagged[atomicAdd(R.n_flagged, 1u)] = static_cast<unsigned>(frame);
     if (!R.list_units_now) return;     // device path: only frames whose stage 1 fails ask for the re-decodes
     for (int cw = 0; cw < 4; ++cw) {
-        unsigned fc = static_cast<unsigned>(frame) * 4u + cw;
+        unsigned fc = static_cast<unsigned>(frame) * 4u + cw, mask = 0;
         for (int f = 1; f <= 4; ++f)
-            if (R.d.res[fc].state[f] == 0) R.list2[atomicAdd(R.n_list2, 1u)] = (fc << 3) | static_cast<unsigned>(f);
+            if (R.d.res[fc].state[f] == 0) mask |= 1u << (f - 1);
+        if (mask) R.list2[atomicAdd(R.n_list2, 1u)] = (fc << 4) | mask;
     }
 }
 template <class S>
@@ -504,12 +505,24 @@ __global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
     if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, R.d.c, smem, threadIdx.x);
-    for (;;) {   // persistent waves over an atomic queue (all-lane atomic form: see fast_phase0_kernel)
+    unsigned guard = 0;
+    for (;;) {   // persistent waves over an atomic queue (all-lane pop, bounded: see RIA_QUEUE_GUARD)
+        RIA_QUEUE_GUARD(guard, total, R.d.ctl)
         unsigned u = atomicAdd(R.next_fill, threadIdx.x == 0 ? 1u : 0u);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= total) break;
-        const unsigned e = R.list2[u];
-        fast_unit(st, R.d, smem, e >> 3, static_cast<int>(e & 7u), threadIdx.x);
+        // one unit = one codeword: its soft bits are gathered from the frame once, then every factor it still lacks
+        const unsigned e = R.list2[u], fc = e >> 4;
+        const FastCode& c = R.d.c;
+        const int lane = threadIdx.x;
+        fast_gather_llr(st, c, R.d.llr + static_cast<size_t>(fc >> 2) * R.d.llr_stride, R.d.gather, fc & 3, lane);
+        for (int f = 1; f <= 4; ++f) {
+            if (!((e >> (f - 1)) & 1u)) continue;
+            bool ok;
+            const int it = fast_decode<S>(st, c, smem, kFactors[f], c.max_iter, lane, &ok);
+            if (ok) fast_pack(st, c, smem, R.d.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw, c.bytes_per_cw, lane);
+            if (lane == 0) { R.d.res[fc].state[f] = ok ? 2 : 1; R.d.res[fc].iters[f] = static_cast<uint16_t>(it); }
+        }
     }
 }
 // one workgroup per flagged frame: compact copies of everything the host stage reads
@@ -589,19 +602,23 @@ __global__ __launch_bounds__(64) void recovery_stage1_kernel(RecoveryArgs R) {
     if (x.dbg && lane == 0) { x.dbg[6] = __builtin_readcyclecounter(); x.dbg[5] = static_cast<unsigned long long>(good); }
     if (good == kRecOverflow) return;   // cannot happen: the array holds every bit of the frame
     if (good) { rec_publish(x, R, frame, info, true, lane); return; }
-    // queue the (codeword, factor) decodes the fallback still misses: lanes 0..15 = (codeword, factor) pairs, ONE
-    // reservation per frame on the shared counter (a counter bumped once per entry by thousands of waves serialises)
-    const unsigned fc = frame * 4u + static_cast<unsigned>(lane >> 2);
+    // queue the decodes the fallback still misses, one entry per codeword (mask of its missing factors): lanes 0..15 =
+    // (codeword, factor) pairs, ONE reservation per frame on the shared counter (a counter bumped once per entry by
+    // thousands of waves serialises)
+    const unsigned fc = frame * 4u + static_cast<unsigned>((lane >> 2) & 3);
     const int f = 1 + (lane & 3);
     const bool need = lane < 16 && R.d.res[fc].state[f] == 0;
     const unsigned long long mk = __ballot(need);
+    const unsigned mine = static_cast<unsigned>(mk >> (lane & 12)) & 15u;          // the four factor bits of this lane's codeword
+    const bool writer = lane < 16 && (lane & 3) == 0 && mine != 0u;
+    const unsigned long long wk = __ballot(writer);
     unsigned base = 0;
     if (lane == 0) {
         R.stage2[atomicAdd(R.n_stage2, 1u)] = frame;
-        if (mk) base = atomicAdd(R.n_list2, static_cast<unsigned>(__popcll(mk)));
+        if (wk) base = atomicAdd(R.n_list2, static_cast<unsigned>(__popcll(wk)));
     }
     base = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
-    if (need) R.list2[base + __popcll(mk & ((1ull << lane) - 1ull))] = (fc << 3) | static_cast<unsigned>(f);
+    if (writer) R.list2[base + __popcll(wk & ((1ull << lane) - 1ull))] = (fc << 4) | mine;
 }
 
 // Stage 2 (frame_v2.cpp:1836-1866): factors 0.75, 0.625, 0.5, 0.875 = kFactors[2, 3, 4, 1]; stage 1 left the

@@ -1305,6 +1305,18 @@ int ria_gpu_ldpc_encode_host(ria_gpu_handle h, const uint8_t* info, int n_cw, ui
     return RIA_OK;
 }
 
+int ria_gpu_debug_queue_fault(ria_gpu_handle h) {
+    if (!h) return RIA_ERR_INVALID;
+    if (!h->d_ctl) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DecodeCtl c[kMaxParts];
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(c, h->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (const DecodeCtl& q : c) bad |= q.queue_fault ? 1 : 0;
+    return bad;
+}
+
 int ria_gpu_debug_math(ria_gpu_handle h, int op, const float* a_dev, const float* b_dev, int n, float* out_dev,
                        void* stream) {
     if (!h || !a_dev || !out_dev || n < 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_debug_math: bad argument");

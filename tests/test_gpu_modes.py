@@ -97,6 +97,7 @@ def test_rx_batch_split_modes_are_bit_identical_and_match_the_reference(oracle):
     th = [threading.Thread(target=work, args=(k * len(sample) // nt, (k + 1) * len(sample) // nt)) for k in range(nt)]
     [t.start() for t in th]; [t.join() for t in th]
     assert not bad, bad[:8]
+    assert e.lib.ria_gpu_debug_queue_fault(e.h) == 0, "a persistent work-queue loop left through its iteration bound"
     e.close()
 
 
@@ -348,3 +349,41 @@ def test_adaptive_ladder_sweep_table():
                 assert r[1] <= trials // 4, (ch, snr, r)
     fer = {k: v[1] / trials for k, v in rows.items()}
     print("ladder table:", {f"{k[0]}:{k[1]:+.0f}": (modes[k], round(fad[k], 2), round(fer[k], 3), round(rows[k][5] / trials, 2)) for k in rows})
+
+
+def test_config_c2_dqpsk_demod_only_full_size(oracle):
+    """BASELINE config 2 at its full size: OFDM DQPSK R1/2, 10 000 frames, AWGN, FFT + LLR kernels only
+    (ria_gpu_demod_batch).  Every 200th frame's 2 650 soft bits and estimator scalars bit-identical to the oracle's
+    processPresynced; size-independent property over the whole batch: the hard decisions of the soft bits, differentially
+    consistent with the transmitted coded bits at 15 dB (few bit errors per frame).  Reports the demodulator's rate on
+    this shape against its algorithmic bytes (31 104 x 4 in + 2 650 x 4 out per frame)."""
+    import torch
+    from ria_amd.engine import RxEngine
+    e = RxEngine("DQPSK", "R1_2", max_batch=10000)
+    n = 10000
+    info = e.make_frames(777, 0, n)
+    x = e.tx(info, peak=0.8)
+    e.channel_exact_(x, 0, 15.0, 777)
+    assert x.shape[1] == 31104 and e.geo.llrs_per_frame == 2650
+    llr, st = e.demod(x)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        llr, st = e.demod(x)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 5
+    algo = n * (31104 * 4 + 2650 * 4)
+    print(f"C2 demod only: {n / ms * 1e3:.0f} frames/s, {algo / ms / 1e6:.1f} GB/s algorithmic ({algo / ms / 1e6 / 8000 * 100:.2f} % of the HBM peak), {ms:.3f} ms per 10 000 frames")
+    L = llr.cpu().numpy()
+    xs = x[::200].cpu().numpy()
+    fs = e.frame_status(st)
+    for q, f in enumerate(range(0, n, 200)):
+        lo, aux = oracle.rx_process(po.DQPSK, po.R1_2, xs[q])
+        assert np.array_equal(bits(L[f]), bits(lo)), f
+        assert np.float32(aux.noise_variance) == fs["noise_variance"][f] and np.float32(aux.fading_index) == fs["fading_index"][f]
+    # whole batch: decode everything (AWGN 15 dB: essentially every frame), payload equals what was transmitted
+    out, dst = e.decode(llr)
+    ok = (out == info).all(dim=1).float().mean().item()
+    assert ok > 0.97, ok
