@@ -129,7 +129,7 @@ int  ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out);
 /* Execution knobs of a handle.  None of them changes a result; the parity tests run the fused call under every
  * value and compare.
  *   RIA_OPT_SPLIT_PARTS  ria_gpu_rx_batch cuts a batch of >= 4096 frames into this many parts that run on internal
- *                        streams (1..4; 1 = one stream, no overlap; 0 = library default, which the environment
+ *                        streams (1..4; 1 = one stream, no overlap; 0 = library default (3), which the environment
  *                        variables RIA_SPLIT_PARTS / RIA_NO_SPLIT may override). */
 #define RIA_OPT_SPLIT_PARTS 1
 /*   RIA_OPT_DUAL_DECODER the retry kernels (phase 0, cascade) decode two codewords per wavefront on an interleaved LDS

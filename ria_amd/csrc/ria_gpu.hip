@@ -701,15 +701,16 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
         return fail(h, RIA_ERR_INVALID, "ria_gpu_rx_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // Demodulate (LLRs stay in the HBM workspace / L2), then decode.  A large chunk is cut in two halves that run
-    // on two internal streams: the low-occupancy phases of one half (first decodes, phase 0, finalise, CRC
-    // recovery: 55-65 % VALU busy) overlap with the cascade of the other.  Results do not depend on the split.
+    // Demodulate (LLRs stay in the HBM workspace / L2), then decode.  A large chunk is cut in parts (default 3) that run
+    // on internal streams: the low-occupancy phases of one part (first decodes, phase 0, finalise, CRC recovery)
+    // overlap with the cascade of another.  Results do not depend on the split
+    // (tests/test_gpu_modes.py::test_rx_batch_split_modes_are_bit_identical_and_match_the_reference).
     const char* rh = getenv("RIA_RECOVERY_HOST");
     const bool single_stream_only = (rh && rh[0] == '1') || getenv("RIA_DEBUG_SYNC") != nullptr;   // host recovery / stage tracing own slot 0
-    int want_parts = h->split_parts;              // per handle (ria_gpu_set_option); 0: environment, else the default 2
+    int want_parts = h->split_parts;              // per handle (ria_gpu_set_option); 0: environment, else the default 3
     if (want_parts == 0) {
         const char* sp = getenv("RIA_SPLIT_PARTS");
-        want_parts = getenv("RIA_NO_SPLIT") ? 1 : sp ? std::max(1, std::min(kMaxParts, atoi(sp))) : 2;
+        want_parts = getenv("RIA_NO_SPLIT") ? 1 : sp ? std::max(1, std::min(kMaxParts, atoi(sp))) : 3;
     }
     if (single_stream_only) want_parts = 1;
     for (int done = 0; done < n_frames;) {

@@ -27,7 +27,7 @@ def _bench_batch(e, n, first, seed=20261004, kind=2, snr=20.0):
 
 def test_rx_batch_split_modes_are_bit_identical_and_match_the_reference(oracle):
     """The bench's own execution mode: ria_gpu_rx_batch cuts a batch of >= 4096 frames into parts on internal
-    streams that share one workspace (slots / offsets).  9 000 faded bench frames through the default split (2), 3
+    streams that share one workspace (slots / offsets).  9 000 faded bench frames through the default split (3), 2
     and 4 parts and the single-stream path, each twice on the same handle (workspace reuse): payload bytes and every
     ria_decode_status field identical across all runs; a 640-frame sample spread over the part boundaries equals
     oracle.decode_fixed_frame (restatement of frame_v2.cpp:1335-1883) on the GPU's own LLRs, the LLRs equal
@@ -38,7 +38,7 @@ def test_rx_batch_split_modes_are_bit_identical_and_match_the_reference(oracle):
     n, first = 9000, 25000 * 5 + 321
     info, x = _bench_batch(e, n, first)
     runs = {}
-    for parts in (1, 0, 3, 4, 2, 1):          # 0 = library default (2 unless the environment says otherwise)
+    for parts in (1, 0, 3, 4, 2, 1):          # 0 = library default (3 unless the environment says otherwise)
         e.set_split_parts(parts)
         for rep in range(2):
             out, st = e.rx(x)
