@@ -156,6 +156,17 @@ def main(argv=None, engine_factory=None):
     if rehearse:
         local = 0
     own_group = False
+    # RIA_BENCH_FORCE_DIST=1: initialise the process group even for ONE rank, so that the RCCL calls of the N > 1 path
+    # (broadcast of the seed, all-reduce of counters and time, barrier) run on real hardware on a one-GPU box
+    force_dist = os.environ.get("RIA_BENCH_FORCE_DIST") == "1"
+    if force_dist and world == 1 and not stub and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        own_group = True
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         own_group = True
@@ -171,8 +182,9 @@ def main(argv=None, engine_factory=None):
     cdev = torch.device("cpu") if (rehearse or stub) else dev      # where the few-byte collectives live
 
     # seed broadcast (the only data-path-adjacent collective: tens of bytes over xGMI)
+    collectives = world > 1 or (dist.is_available() and dist.is_initialized())
     seed_t = torch.tensor([args.seed], dtype=torch.int64, device=cdev)
-    if world > 1:
+    if collectives:
         dist.broadcast(seed_t, 0)
     seed = int(seed_t.item())
 
@@ -196,7 +208,7 @@ def main(argv=None, engine_factory=None):
 
     def barrier():
         device_sync()
-        if world > 1:
+        if collectives:
             dist.barrier()
         device_sync()
 
@@ -215,7 +227,7 @@ def main(argv=None, engine_factory=None):
     bytes_ok = int((out[0] == infos[(n_sets - 1) % n_pool]).all(dim=1).sum().item())
     cnt = torch.tensor([B * args.steps, frames_ok, bytes_ok, int(st["iterations"].sum())], dtype=torch.int64, device=cdev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if collectives:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())

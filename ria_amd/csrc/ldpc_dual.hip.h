@@ -323,7 +323,7 @@ struct CascadeOps {
         uint32_t* mt = reinterpret_cast<uint32_t*>(lds) + C;
         float* normal = reinterpret_cast<float*>(lds) + C + 2 * 640;
         wave_sync();
-        if (!(A.flags & 0x8000u)) normal648_wave<2>(mt, normal, seed, lane);   // 0x8000: timing experiment (tools/exp_*), never set by the ABI
+        normal648_wave<2>(mt, normal, seed, lane);
         auto tf = [&](float v, float nz) {
             if (kind == 1) { v = (v < 10.0f) ? v : 10.0f; v = (-10.0f < v) ? v : -10.0f; }
             else if (kind == 2) v = v * 0.5f;

@@ -688,10 +688,10 @@ __global__ void fast_chain_kernel(FastDecodeArgs A) {
 // perturbed decoder input of cascade attempt a (frame_v2.cpp:1415-1546) into st.li/st.lp
 template <class S>
 __device__ inline float fast_perturb(FastState<S>& st, const FastCode& c, const float* base_i, const float* base_p,
-                                     uint32_t* mt, float* normal, int a, uint32_t h, int lane, bool exp_skip_rng = false) {
+                                     uint32_t* mt, float* normal, int a, uint32_t h, int lane) {
     uint32_t seed; float sigma, factor; int kind;
     retry_transform_params(a, h, &seed, &sigma, &factor, &kind);
-    if (!exp_skip_rng) normal648_wave(mt, normal, seed, lane);   // exp_skip_rng: timing experiment only (tools/exp_*)
+    normal648_wave(mt, normal, seed, lane);
     auto tf = [&](float v, float nz) {
         if (kind == 1) { v = (v < 10.0f) ? v : 10.0f; v = (-10.0f < v) ? v : -10.0f; }
         else if (kind == 2) v = v * 0.5f;
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
 #pragma unroll
         for (int r = 0; r < S::NR; ++r) bp[r] = st.lp[r];
         const uint32_t h = A.l1hash[li];
-        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane, (A.flags & 0x8000u) != 0);
+        float factor = fast_perturb(st, c, bi, bp, reinterpret_cast<uint32_t*>(msg), msg + 640, static_cast<int>(a), h, lane);
         bool ok;
         const int it = fast_decode<S, S::kCascadeCv>(st, c, smem, factor, c.max_iter, lane, &ok);
         if (ok) {

@@ -590,8 +590,7 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     A.llr = llr_dev;
     A.llr_stride = llr_stride;
     A.n_frames = n_frames;
-    A.flags = flags & 0x7fffu;
-    if (getenv("RIA_EXP_NO_RNG")) A.flags |= 0x8000u;   // developer timing experiment: wrong results
+    A.flags = flags;
     A.info_out = info_out_dev;
     A.status = status_dev;
     A.crc_bit = static_cast<const uint16_t*>(h->d_crc_bit);

@@ -387,3 +387,19 @@ def test_config_c2_dqpsk_demod_only_full_size(oracle):
     out, dst = e.decode(llr)
     ok = (out == info).all(dim=1).float().mean().item()
     assert ok > 0.97, ok
+
+
+def test_bench_rccl_code_path_on_one_rank():
+    """bench.py's N > 1 collectives (RCCL broadcast of the seed, all-reduce of counters and time, barrier) executed on this
+    box's GPU with a one-rank process group (RIA_BENCH_FORCE_DIST=1): the line must carry the same metric and workload as
+    the plain run.  (A real N > 1 run needs an N-GPU node: the driver's job.)"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RIA_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["unit"] == "frames/s" and line["value"] > 1e5
+    assert line["config"]["frames_decoded_last_step"] > 2000

@@ -842,6 +842,24 @@ def test_edge_cases():
     cw = torch.full((4, 648), 20.0, device="cuda")
     out, ok, it = e.ldpc_decode(cw, 80, 0.9375)
     assert ok.all() and (it == 0).all() and (out == 0).all()
+    # a batch whose workspace cannot be allocated fails with an error status (no launch on half-built buffers), and the
+    # handle keeps working afterwards (ensure_decode_ws drops its frame count before it frees anything)
+    import ctypes as C
+    from ria_amd import capi
+    from ria_amd.engine import RxEngine
+    e2 = RxEngine("QAM16", "R1_2", max_batch=64)
+    small = torch.zeros((8, 2632), dtype=torch.float32, device="cuda")
+    info8 = torch.empty((8, 160), dtype=torch.uint8, device="cuda")
+    st8 = torch.zeros((8, 20), dtype=torch.uint8, device="cuda")
+    absurd = 1 << 30     # 4 * 2^30 codeword slots of several hundred bytes each: far beyond 288 GB
+    rc = e2.lib.ria_gpu_decode_batch(e2.h, C.c_void_p(small.data_ptr()), 2632, absurd, capi.DECODE_FULL, C.c_void_p(info8.data_ptr()),
+                                     C.c_void_p(st8.data_ptr()), None)
+    assert rc == -3 and b"workspace" in e2.lib.ria_gpu_last_error(e2.h)
+    llr8 = torch.full((8, 2632), 5.0, device="cuda")
+    out8, s8 = e2.decode(llr8)
+    torch.cuda.synchronize()
+    assert e2.decode_status(s8)["cw_ok"].all()
+    e2.close()
 
 
 def test_cpp_host_adaptor_drop_in(golden, tmp_path):
