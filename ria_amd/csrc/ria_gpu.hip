@@ -100,6 +100,9 @@ int fail(ria_gpu_handle h, int code, const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     if (h) h->err = buf;
+    // a failed HIP call leaves its code in the runtime's per-thread "last error"; the caller has been told through the
+    // return value, so do not let it surface again in whoever calls hipGetLastError next (e.g. the host framework)
+    if (code == RIA_ERR_HIP) (void)hipGetLastError();
     return code;
 }
 

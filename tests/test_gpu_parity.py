@@ -856,9 +856,9 @@ def test_edge_cases():
                                      C.c_void_p(st8.data_ptr()), None)
     assert rc == -3 and b"workspace" in e2.lib.ria_gpu_last_error(e2.h)
     llr8 = torch.full((8, 2632), 5.0, device="cuda")
-    out8, s8 = e2.decode(llr8)
+    out8, s8 = e2.decode(llr8, flags=capi.DECODE_PHASE0 | capi.DECODE_PERTURB)   # all-zero codewords converge at once (no valid frame inside)
     torch.cuda.synchronize()
-    assert e2.decode_status(s8)["cw_ok"].all()
+    assert e2.decode_status(s8)["cw_ok"].all() and (out8 == 0).all()
     e2.close()
 
 
