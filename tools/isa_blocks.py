@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/isa/ria.s"
 os.makedirs("/tmp/isa", exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                "-fhip-fp32-correctly-rounded-divide-sqrt", "-std=c++17", "--cuda-device-only", "-S",
+                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-std=c++17", "--cuda-device-only", "-S",
                 os.path.join(root, "ria_amd/csrc/ria_gpu.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
 pat = sys.argv[1]
