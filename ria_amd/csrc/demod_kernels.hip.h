@@ -418,12 +418,31 @@ __device__ __forceinline__ float cfo_phase_step8(float th, float inc) {
 
 // Symbol s of the frame: CFO correction phases (if any), downconversion, FFT; the 59 used bins go to Yrow.
 // th_walk (meaningful on lane 0): correction phase at the first sample of this symbol on entry, of the next on exit.
-__device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float* __restrict__ x, int s, float2* buf, float2* Yrow,
-                                                 DemodShared* sh, int lane, float& th_walk) {
+// Sample prefetch: while the estimator works on symbol s the FFT tile is idle, so the 1024 samples of the NEXT symbol are
+// fetched straight into it by LDS-DMA (global_load_lds_dwordx4: 4 wave-instructions, no VGPRs): floats [kRawOff, kRawOff +
+// 1024) of the tile, behind the 1152 floats the CFO path uses for its phases.  pf_sym (wave-uniform) = the symbol whose
+// samples are in flight / have landed there, -1 none; the staging step then reads the tile instead of HBM (a frame's
+// sample loads were 21 % of the kernel's time: measured by letting every frame read cache-resident samples).
+constexpr int kRawOff = 1152;
+__device__ __forceinline__ void demod_prefetch_symbol(const float* __restrict__ x, int s, float2* buf, int lane) {
+    const float* xs = x + s * kSym + kCP;
+    float* raw = reinterpret_cast<float*>(buf) + kRawOff;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + 4 * lane + 256 * c),
+                                         (__attribute__((address_space(3))) void*)(raw + 256 * c), 16, 0, 0);
+}
+
+__device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float* __restrict__ x, int s, int next_s, float2* buf, float2* Yrow,
+                                                 DemodShared* sh, int lane, float& th_walk, int& pf_sym) {
     const float cfo = sh->cfo;
     const bool use_cfo = fabs_(cfo) > 0.01f;
     const float inc = static_cast<float>(-2.0f * 3.14159265358979323846 * static_cast<double>(cfo) / 48000.0);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    if (pf_sym >= 0) {   // a prefetch is in flight or has landed: it must be complete before the tile is read or rewritten
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+    }
     float th_reg[16];
     if (use_cfo) {
         // channel_equalizer.cpp:132-144: float phase recurrence over EVERY sample (CP included), wrapped
@@ -451,14 +470,28 @@ __device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float
             for (int e = 0; e < 4; ++e) th_reg[4 * c + e] = thb[kCP + 4 * lane + 256 * c + e];
         wave_sync();
     }
-    // stage + downconvert 1024 samples (cyclic prefix dropped): 16 B per lane per load, coalesced
+    // stage + downconvert 1024 samples (cyclic prefix dropped): 16 B per lane per load, coalesced; from the tile when the
+    // previous symbol's step prefetched them (all 16 floats of the lane are read before the tile is written below)
     const float* xs = x + s * kSym + kCP;
     const float2* osc = A.nco + s * kSym + kCP;
+    const bool from_tile = (pf_sym == s);
+    float xa[16];
+    if (from_tile) {
+        const float* raw = reinterpret_cast<const float*>(buf) + kRawOff;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(raw + 4 * lane + 256 * c);
+            xa[4 * c] = v.x; xa[4 * c + 1] = v.y; xa[4 * c + 2] = v.z; xa[4 * c + 3] = v.w;
+        }
+        wave_sync();
+    }
+    pf_sym = -1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         int j = 4 * lane + 256 * c;
         float xv[4];
-        if (aligned) { float4 v = *reinterpret_cast<const float4*>(xs + j); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+        if (from_tile) { xv[0] = xa[4 * c]; xv[1] = xa[4 * c + 1]; xv[2] = xa[4 * c + 2]; xv[3] = xa[4 * c + 3]; }
+        else if (aligned) { float4 v = *reinterpret_cast<const float4*>(xs + j); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
         else { xv[0] = xs[j]; xv[1] = xs[j + 1]; xv[2] = xs[j + 2]; xv[3] = xs[j + 3]; }
         const float4 o01 = *reinterpret_cast<const float4*>(osc + j), o23 = *reinterpret_cast<const float4*>(osc + j + 2);
         const float2 ov[4] = {make_float2(o01.x, o01.y), make_float2(o01.z, o01.w), make_float2(o23.x, o23.y), make_float2(o23.z, o23.w)};
@@ -471,6 +504,7 @@ __device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float
     }
     wave_sync();
     fft1024_wave(buf, A.twiddle, Yrow, lane);
+    if (aligned && next_s >= 0) { demod_prefetch_symbol(x, next_s, buf, lane); pf_sym = next_s; }
 }
 
 __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3))) void demod_frames_kernel(DemodArgs A) {
@@ -526,6 +560,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
     float* T = sh->sums;
     float* TP = sh->psums;
     float th_walk = 0.0f;
+    int pf_sym = -1;
     const float2 txv = make_float2(K.tx_re[lane], K.tx_im[lane]);
     const float lsign = negate_lts0 ? -1.0f : 1.0f;
     float2 H0 = make_float2(0, 0), H1 = make_float2(0, 0);
@@ -535,8 +570,8 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
         // ---- the two training symbols through the FFT with the current CFO (pass 1: mixer.reset(), phase
         // restored to its value at training start, corrected CFO: channel_equalizer.cpp:337-344)
         th_walk = sh->theta0;
-        demod_fft_symbol(A, x, 0, tiles, Y, sh, lane, th_walk);
-        demod_fft_symbol(A, x, 1, tiles, Y + 64, sh, lane, th_walk);
+        demod_fft_symbol(A, x, 0, 1, tiles, Y, sh, lane, th_walk, pf_sym);
+        demod_fft_symbol(A, x, 1, 2 < n_sym ? 2 : -1, tiles, Y + 64, sh, lane, th_walk, pf_sym);   // (a re-run asks for symbol 0 instead: the prefetch is dropped)
         if (A.dbg && pass == 0) t1 = __builtin_readcyclecounter();
         {
             float2 y0 = Y[0 * 64 + lane], y1 = Y[1 * 64 + lane];
@@ -637,7 +672,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
         const float2 rot_res = make_float2(cosf_glibc(ph_res), sinf_glibc(ph_res));
 
         for (int ds = 0; ds < K.n_data_symbols; ++ds) {
-            demod_fft_symbol(A, x, 2 + ds, tiles, Y + 128, sh, lane, th_walk);
+            demod_fft_symbol(A, x, 2 + ds, 3 + ds < n_sym ? 3 + ds : -1, tiles, Y + 128, sh, lane, th_walk, pf_sym);
             float2 y = Y[128 + lane];
             const bool first = (ds == 0);
             // ---------- updateChannelEstimate (channel_equalizer.cpp:645-1043)
