@@ -64,7 +64,7 @@ struct ShapeR14 {   // m = 486, k = 162
 struct ShapeR23 {   // m = 216, k = 432
     static constexpr int NR = 4, NC = 7;
     static constexpr int kCascadeWaves = 3;   // waves/SIMD the cascade kernel is held to (its register budget)
-    static constexpr int kCv = 0;   // the row's own c2v words of slot groups < kCv stay in VGPRs between iterations (their LDS re-reads saved) as the register budget allows
+    static constexpr int kCv = 24;   // the row's own c2v words of slot groups < kCv stay in VGPRs between iterations (their LDS re-reads saved) as the register budget allows
     static constexpr int ne(int r) { constexpr int t[NR] = {6, 6, 6, 6}; return t[r]; }
     static constexpr int nm(int r) { constexpr int t[NR] = {6, 6, 6, 4}; return t[r]; }
     static constexpr int dv(int r) { constexpr int t[NC] = {3, 3, 3, 3, 3, 3, 3}; return t[r]; }
