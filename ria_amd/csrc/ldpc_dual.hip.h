@@ -175,6 +175,7 @@ __device__ inline void dual_pack(const FastCode& c, unsigned char* lds, uint8_t*
     unsigned char* scratch = lds + 8 * I::dump_word;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(scratch);
     const int nr = (c.k + 63) / 64;
+    lane = opaque_lane(lane);
     wave_sync();
     for (int r = 0; r < nr; ++r) {
         const int j = lane + 64 * r;
@@ -236,6 +237,7 @@ __device__ inline void dual_decode_loop(DualState<S>& st, const FastCode& c, uns
 
 template <class S, int C>
 __device__ inline void dual_load_staged(DualState<S>& st, const float* __restrict__ src, int lane) {
+    lane = opaque_lane(lane);
 #pragma unroll
     for (int r = 0; r < S::NC; ++r) st.li[r][C] = src[r * 64 + lane];
 #pragma unroll
@@ -312,6 +314,7 @@ struct CascadeOps {
         const unsigned fcw = A.entries[e[C]];
         const unsigned li = A.l1idx[fcw];
         const float* src = A.staged + static_cast<size_t>(li) * kStageFloats;
+        const int lane = opaque_lane(this->lane);   // per-unit indices and addresses are recomputed, not hoisted (ldpc_fast.hip.h)
         float bi[S::NC], bp[S::NR];
 #pragma unroll
         for (int r = 0; r < S::NC; ++r) bi[r] = src[r * 64 + lane];
