@@ -290,6 +290,9 @@ def main(argv=None, engine_factory=None):
                                            "frac": round(dec_insts / (t_decode * 1e-3) / VALU_PEAK_INSTS, 4)},
                           "fused_step": {"insts_per_step": int(all_insts), "ms": round(elapsed / args.steps * 1e3, 3),
                                          "frac": round(all_insts / (elapsed / args.steps) / VALU_PEAK_INSTS, 4)},
+                          "model": "one VALU instruction per SIMD per 4 cycles (what a single wave sees); with several waves a SIMD retires "
+                                   "two-operand instructions faster and three-operand / packed ones at about this rate "
+                                   "(tools/probes/valu_rate_probe.hip), so frac bounds the VALU occupancy from above",
                           "source": sq_path + " (instruction counts; the times are this run's)"}
         else:
             valu = {"source": sq_path if sq is None else f"{sq_path}: other batch size"}
