@@ -172,9 +172,24 @@ __device__ __forceinline__ void bfly(float2& a, float2& b, float2 w) {  // fft.c
     a = make_float2(a.x + t.x, a.y + t.y);
 }
 
+// The 15 twiddles of stages 1-4 are the same for every lane and every symbol: loaded once per frame into scalar registers
+// (inside the symbol loop the compiler has to use vector loads for them: the kernel has stored to global memory by then).
+struct FftUniformTw { float2 w[15]; };   // stage s (1..4), k in [0, 2^(s-1)): w[(1 << (s - 1)) - 1 + k] = tw[k << (10 - s)]
+__device__ __forceinline__ FftUniformTw fft_load_uniform_tw(const float2* __restrict__ tw) {
+    FftUniformTw u;
+#pragma unroll
+    for (int s = 1; s <= 4; ++s)
+#pragma unroll
+        for (int k = 0; k < (1 << (s - 1)); ++k) {
+            const float2 v = tw[k << (10 - s)];
+            u.w[(1 << (s - 1)) - 1 + k] = make_float2(u2f(__builtin_amdgcn_readfirstlane(f2u(v.x))), u2f(__builtin_amdgcn_readfirstlane(f2u(v.y))));
+        }
+    return u;
+}
+
 // buf[0..1023] holds the time samples in natural order on entry (plain layout).  On exit the 59 used
 // bins are written to Yrow[logical carrier].
-__device__ inline void fft1024_wave(float2* buf, const float2* __restrict__ tw, float2* Yrow, int lane) {
+__device__ inline void fft1024_wave(float2* buf, const float2* __restrict__ tw, const FftUniformTw& utw, float2* Yrow, int lane) {
     float2 x[16];
     // pass 1: bit-reversed gather, stages 1-4 on indices 16*lane + r
     {
@@ -193,7 +208,7 @@ __device__ inline void fft1024_wave(float2* buf, const float2* __restrict__ tw, 
         for (int r = 0; r < 16; ++r) {
             if ((r & half) == 0) {
                 int k = r & (half - 1);
-                bfly(x[r], x[r + half], tw[k << (10 - s)]);
+                bfly(x[r], x[r + half], utw.w[half - 1 + k]);
             }
         }
     }
@@ -434,7 +449,7 @@ __device__ __forceinline__ void demod_prefetch_symbol(const float* __restrict__ 
 }
 
 __device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float* __restrict__ x, int s, int next_s, float2* buf, float2* Yrow,
-                                                 DemodShared* sh, int lane, float& th_walk, int& pf_sym) {
+                                                 DemodShared* sh, int lane, float& th_walk, int& pf_sym, const FftUniformTw& utw) {
     const float cfo = sh->cfo;
     const bool use_cfo = fabs_(cfo) > 0.01f;
     const float inc = static_cast<float>(-2.0f * 3.14159265358979323846 * static_cast<double>(cfo) / 48000.0);
@@ -503,7 +518,7 @@ __device__ __forceinline__ void demod_fft_symbol(const DemodArgs& A, const float
         }
     }
     wave_sync();
-    fft1024_wave(buf, A.twiddle, Yrow, lane);
+    fft1024_wave(buf, A.twiddle, utw, Yrow, lane);
     if (aligned && next_s >= 0) { demod_prefetch_symbol(x, next_s, buf, lane); pf_sym = next_s; }
 }
 
@@ -561,6 +576,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
     float* TP = sh->psums;
     float th_walk = 0.0f;
     int pf_sym = -1;
+    const FftUniformTw utw = fft_load_uniform_tw(A.twiddle);
     const float2 txv = make_float2(K.tx_re[lane], K.tx_im[lane]);
     const float lsign = negate_lts0 ? -1.0f : 1.0f;
     float2 H0 = make_float2(0, 0), H1 = make_float2(0, 0);
@@ -570,8 +586,8 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
         // ---- the two training symbols through the FFT with the current CFO (pass 1: mixer.reset(), phase
         // restored to its value at training start, corrected CFO: channel_equalizer.cpp:337-344)
         th_walk = sh->theta0;
-        demod_fft_symbol(A, x, 0, 1, tiles, Y, sh, lane, th_walk, pf_sym);
-        demod_fft_symbol(A, x, 1, 2 < n_sym ? 2 : -1, tiles, Y + 64, sh, lane, th_walk, pf_sym);   // (a re-run asks for symbol 0 instead: the prefetch is dropped)
+        demod_fft_symbol(A, x, 0, 1, tiles, Y, sh, lane, th_walk, pf_sym, utw);
+        demod_fft_symbol(A, x, 1, 2 < n_sym ? 2 : -1, tiles, Y + 64, sh, lane, th_walk, pf_sym, utw);   // (a re-run asks for symbol 0 instead: the prefetch is dropped)
         if (A.dbg && pass == 0) t1 = __builtin_readcyclecounter();
         {
             float2 y0 = Y[0 * 64 + lane], y1 = Y[1 * 64 + lane];
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
         const float2 rot_res = make_float2(cosf_glibc(ph_res), sinf_glibc(ph_res));
 
         for (int ds = 0; ds < K.n_data_symbols; ++ds) {
-            demod_fft_symbol(A, x, 2 + ds, 3 + ds < n_sym ? 3 + ds : -1, tiles, Y + 128, sh, lane, th_walk, pf_sym);
+            demod_fft_symbol(A, x, 2 + ds, 3 + ds < n_sym ? 3 + ds : -1, tiles, Y + 128, sh, lane, th_walk, pf_sym, utw);
             float2 y = Y[128 + lane];
             const bool first = (ds == 0);
             // ---------- updateChannelEstimate (channel_equalizer.cpp:645-1043)
