@@ -533,9 +533,6 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
     DemodShared* sh = reinterpret_cast<DemodShared*>(Y + 3 * 64);
 
     const float* x = A.samples + (A.offsets ? A.offsets[frame] : static_cast<uint64_t>(frame) * n_sym * kSym);
-#ifdef RIA_EXP_DEMOD_SAMEFRAME   // timing experiment only: every frame reads frame (id mod 64)'s samples (cache hits): what sample-load latency costs
-    x = A.samples + static_cast<uint64_t>(frame & 63) * n_sym * kSym;
-#endif
     if (threadIdx.x == 0) {
         float cfo = 0.0f;
         double init = 0.0;

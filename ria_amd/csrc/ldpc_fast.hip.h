@@ -139,24 +139,14 @@ struct FastCode {
 #define RIA_ADDTID 0
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef RIA_PK
-#define RIA_PK 0
-#endif
-#ifndef RIA_PACK_ADDR
-#define RIA_PACK_ADDR 0
-#endif
-constexpr bool kPackAddr = RIA_PACK_ADDR != 0;
-constexpr bool kPk = RIA_PK != 0;      // packed-FP32 forms in the decoder core
 constexpr bool kCvRegs = RIA_CV_REGS != 0;
 constexpr bool kAddTid = RIA_ADDTID != 0;
 
 template <class S>
 struct FastState {
     using I = ShapeInfo<S>;
-    // gather addresses of the check pass / of the column pass: LDS byte addresses relative to the wave's region, one per
-    // register, or (kPackAddr) two 16-bit addresses per register, unpacked by a v_and / v_lshrrev next to each use
-    uint32_t rv[kPackAddr ? (I::TS + 1) / 2 : I::TS];
-    uint32_t cs[kPackAddr ? (I::TD + 2) / 2 : (I::TD > 0 ? I::TD : 1)];
+    uint32_t rv[I::TS];            // gather addresses of the check pass
+    uint32_t cs[I::TD > 0 ? I::TD : 1];   // gather addresses of the column pass
     float cv[I::TS];               // c2v of the row's own edges as written in the previous iteration (slots < NCV of fast_decode only)
     float li[S::NC];               // information-column LLRs (sorted position q = lane + 64 r)
     float lp[S::NR];               // identity-column LLRs (row position p = lane + 64 r)
@@ -180,45 +170,11 @@ __device__ __forceinline__ void lds_sf(uint32_t a, float v) { *(lds_float_ptr)(u
 template <class S>
 __device__ inline void fast_load_tables(FastState<S>& st, const FastCode& c, const unsigned char* lds, int lane) {
     using I = ShapeInfo<S>;
-    const uint32_t base = kPackAddr ? 0u : lds_addr(lds);
-    auto ra = [&](int i) -> uint32_t {
-#ifdef RIA_EXP_LINEAR_GATHER   // timing experiment only (wrong results): every gather lane-linear, i.e. free of bank conflicts
-        return 4u * (I::tot_word + 64 * (i % S::NC)) + 4u * lane;
-#endif
-        return c.row_addr[i * 64 + lane];
-    };
-    auto ca = [&](int i) -> uint32_t {
-#ifdef RIA_EXP_LINEAR_GATHER
-        return 256u * (i % I::TS) + 4u * lane;
-#endif
-        return c.col_addr[i * 64 + lane];
-    };
-    if constexpr (kPackAddr) {
+    const uint32_t base = lds_addr(lds);
 #pragma unroll
-        for (int i = 0; i < I::TS; i += 2) { uint32_t a = ra(i) | (i + 1 < I::TS ? ra(i + 1) << 16 : 0u); asm volatile("" : "+v"(a)); st.rv[i / 2] = a; }
+    for (int i = 0; i < I::TS; ++i) { uint32_t a = base + c.row_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.rv[i] = a; }
 #pragma unroll
-        for (int i = 0; i < I::TD; i += 2) { uint32_t a = ca(i) | (i + 1 < I::TD ? ca(i + 1) << 16 : 0u); asm volatile("" : "+v"(a)); st.cs[i / 2] = a; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < I::TS; ++i) { uint32_t a = base + ra(i); asm volatile("" : "+v"(a)); st.rv[i] = a; }
-#pragma unroll
-        for (int i = 0; i < I::TD; ++i) { uint32_t a = base + ca(i); asm volatile("" : "+v"(a)); st.cs[i] = a; }
-    }
-}
-// address i of a (possibly packed) address array; base = LDS address of the wave's region
-template <int i, int N>
-__device__ __forceinline__ uint32_t fast_addr(const uint32_t (&a)[N], uint32_t base) {
-    if constexpr (kPackAddr) return base + ((i & 1) ? (a[i / 2] >> 16) : (a[i / 2] & 0xffffu));
-    else return a[i];
-}
-// once per iteration: the packed words become opaque, so that the unpacked addresses are recomputed next to their use
-// instead of being hoisted out of the iteration loop into registers of their own
-template <int N>
-__device__ __forceinline__ void fast_addr_fence(uint32_t (&a)[N]) {
-    if constexpr (kPackAddr) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
-    }
+    for (int i = 0; i < I::TD; ++i) { uint32_t a = base + c.col_addr[i * 64 + lane]; asm volatile("" : "+v"(a)); st.cs[i] = a; }
 }
 
 // store to LDS word (base/4 + OFF/4 + lane): ds_write_addtid_b32 takes its address from M0 + offset + 4*lane, needs
@@ -242,21 +198,6 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
 // schedules them freely (inline asm costs an s_nop before every dependent instruction: the hazard recogniser has to
 // assume a transcendental).  Operands are results of float arithmetic or of these selections, i.e. canonical, so the
 // IEEE-mode quieting of v_min_f32 never needs a separate instruction.
-#ifndef RIA_ASM_SELECT
-#define RIA_ASM_SELECT 0
-#endif
-#if RIA_ASM_SELECT
-__device__ __forceinline__ float med3_abs(float x, float b, float c) { float d; asm("v_med3_f32 %0, |%1|, %2, %3" : "=v"(d) : "v"(x), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float min_abs(float x, float b) { float d; asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(d) : "v"(x), "v"(b)); return d; }
-__device__ __forceinline__ float min3_abs(float a, float b, float c) { float d; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float med3_abs3(float a, float b, float c) { float d; asm("v_med3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float min2_abs(float a, float b) { float d; asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float max2_abs(float a, float b) { float d; asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float min_raw(float a, float b) { float d; asm("v_min_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float min3_abs1(float a, float b, float c) { float d; asm("v_min3_f32 %0, |%1|, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float min3_abs2(float a, float b, float c) { float d; asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float min3_raw(float a, float b, float c) { float d; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-#else
 __device__ __forceinline__ float med3_abs(float x, float b, float c) { return __builtin_amdgcn_fmed3f(__builtin_fabsf(x), b, c); }
 __device__ __forceinline__ float min_abs(float x, float b) { return __builtin_fminf(__builtin_fabsf(x), b); }
 __device__ __forceinline__ float min3_abs(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
@@ -264,10 +205,6 @@ __device__ __forceinline__ float med3_abs3(float a, float b, float c) { return _
 __device__ __forceinline__ float min2_abs(float a, float b) { return __builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)); }
 __device__ __forceinline__ float max2_abs(float a, float b) { return __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)); }
 __device__ __forceinline__ float min_raw(float a, float b) { return __builtin_fminf(a, b); }
-__device__ __forceinline__ float min3_abs1(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), b), c); }
-__device__ __forceinline__ float min3_abs2(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), c); }
-__device__ __forceinline__ float min3_raw(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
-#endif
 // The two smallest magnitudes of w[0..N-1] (with multiplicity: a repeated minimum gives mid == lo) as a small
 // tournament of 3-input selections instead of the 2-ops-per-element running update: triples give (min3, med3),
 // two (lo, mid) pairs merge as lo = min(l1, l2), mid = med3(l1, l2, min(m1, m2)), a single element joins as
@@ -289,29 +226,6 @@ __device__ __forceinline__ void two_smallest_abs(const float (&w)[N], float& lo,
             if constexpr (N >= 5) { mid = med3_abs(w[4], lo, mid); lo = min_abs(w[4], lo); }
         }
     }
-}
-// The same two values, each passed through min(., hi) (the reference's +-50 clamp of the v2c magnitudes; hi = inf in the
-// first iteration).  min(., hi) is monotone, so it commutes with the selections: the clamp of the smallest rides on the
-// last v_min of the tournament as the third operand of a v_min3 wherever there is one.
-template <int N>
-__device__ __forceinline__ void two_smallest_abs_clamped(const float (&w)[N], float hi, float& lo, float& mid) {
-    static_assert(N >= 2 && N <= 7, "row degree");
-    if constexpr (N == 2) { lo = min3_abs2(w[0], w[1], hi); mid = max2_abs(w[0], w[1]); }
-    else if constexpr (N == 3) { lo = min3_abs(w[0], w[1], w[2]); mid = med3_abs3(w[0], w[1], w[2]); lo = min_raw(lo, hi); }
-    else {
-        lo = min3_abs(w[0], w[1], w[2]); mid = med3_abs3(w[0], w[1], w[2]);
-        if constexpr (N >= 6) {
-            const float l2 = min3_abs(w[3], w[4], w[5]), m2 = med3_abs3(w[3], w[4], w[5]);
-            const float x = min_raw(mid, m2);
-            mid = __builtin_amdgcn_fmed3f(lo, l2, x);
-            if constexpr (N == 7) { lo = min_raw(lo, l2); mid = med3_abs(w[6], lo, mid); lo = min3_abs1(w[6], lo, hi); }
-            else lo = min3_raw(lo, l2, hi);
-        } else {
-            if constexpr (N == 4) { mid = med3_abs(w[3], lo, mid); lo = min3_abs1(w[3], lo, hi); }
-            else { mid = med3_abs(w[3], lo, mid); lo = min_abs(w[3], lo); mid = med3_abs(w[4], lo, mid); lo = min3_abs1(w[4], lo, hi); }
-        }
-    }
-    mid = min_raw(mid, hi);
 }
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // v_bfi_b32
 
@@ -367,19 +281,14 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
     bool success = false;
     for (; it < max_iter; ++it) {
         uint32_t syn = 0;
-        fast_addr_fence(st.rv);
-        fast_addr_fence(st.cs);
         // the total gathers of round r + PF are issued before round r is computed (LDS operations keep their program
         // order: without this every round starts by waiting out an LDS round trip)
         float tt[I::TS];
-        float xid[S::NR];   // identity edge of each row round: sign * min of the others, before the factor
         auto gather_round = [&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value;
             if constexpr (g < S::NR) {
-                static_for<0, S::ne(g)>([&](auto S_) __attribute__((always_inline)) {
-                    constexpr int i = I::row_off(g) + decltype(S_)::value;
-                    tt[i] = lds_f(fast_addr<i>(st.rv, m0base));
-                });
+#pragma unroll
+                for (int s = 0; s < S::ne(g); ++s) tt[I::row_off(g) + s] = lds_f(st.rv[I::row_off(g) + s]);
             }
         };
         static_for<0, PF>([&](auto G_) __attribute__((always_inline)) { gather_round(G_); });
@@ -408,24 +317,11 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             // min(min_k |x_k|, hi), so the tournament runs on the unclamped differences and its two results are
             // clamped (2 operations per row instead of one per edge); min(|x|, min2) below is unchanged by the
             // clamp of x because min2 <= hi.
-            // (differences, the factor products and the column sums go two at a time through v_pk_add_f32 / v_pk_mul_f32:
-            // the packed forms are the IEEE operations of their halves)
-            for (int s = 0; s < NE; s += 2) {
-                if (kPk && s + 1 < NE) {
-                    const v2f d = v2f{t[s], t[s + 1]} - v2f{cold[s], cold[s + 1]};
-                    v[s] = d.x; v[s + 1] = d.y;
-                } else {
-                    v[s] = t[s] - cold[s];
-                    if (s + 1 < NE) v[s + 1] = t[s + 1] - cold[s + 1];
-                }
-            }
+            for (int s = 0; s < NE; ++s) v[s] = t[s] - cold[s];
             v[NE] = pvr;
-            if constexpr (kPk) two_smallest_abs_clamped<NE + 1>(v, hi, min1, min2);
-            else {
-                two_smallest_abs<NE + 1>(v, min1, min2);
-                min1 = min_raw(min1, hi);
-                min2 = min_raw(min2, hi);
-            }
+            two_smallest_abs<NE + 1>(v, min1, min2);
+            min1 = min_raw(min1, hi);
+            min2 = min_raw(min2, hi);
 #pragma unroll
             for (int s = 0; s < NE; s += 2) {             // parity of the hard bits / product of the signs: xor3
                 if (s + 1 < NE) {
@@ -443,81 +339,37 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             // bits(min1) ^ bits(min2) ^ row-sign swaps the magnitude to the other candidate and turns the edge's own
             // sign into the product of the others.  (sign * min_abs) * factor is then the reference's own order.
             const uint32_t dS = bfi(kAbs, f2u(min1) ^ f2u(min2), sgn);
-            float x[NE], o[NE];
-#pragma unroll
-            for (int s = 0; s < NE; ++s) x[s] = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(v[s], min2, -min2)));
-#pragma unroll
-            for (int s = 0; s < NE; s += 2) {
-                if (kPk && s + 1 < NE) {
-                    const v2f q = v2f{x[s], x[s + 1]} * v2f{factor, factor};
-                    o[s] = q.x; o[s + 1] = q.y;
-                } else {
-                    o[s] = x[s] * factor;
-                    if (s + 1 < NE) o[s + 1] = x[s + 1] * factor;
-                }
-            }
             static_for<0, NE>([&](auto S_) __attribute__((always_inline)) {
                 constexpr int s = decltype(S_)::value;
-                lds_store_tid<256 * (off + s)>(m0base, o[s]);
-                if constexpr (off + s < NCV) st.cv[off + s] = o[s];
+                const float o = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(v[s], min2, -min2))) * factor;
+                lds_store_tid<256 * (off + s)>(m0base, o);
+                if constexpr (off + s < NCV) st.cv[off + s] = o;
             });
-            xid[r] = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(pvr, min2, -min2)));
-        });
-        // identity columns: degree 1, total = llr + c2v, v2c = clamp(total - c2v) (clamped where it is used, see above)
-#pragma unroll
-        for (int r = 0; r < S::NR; r += 2) {
-            if (kPk && r + 1 < S::NR) {
-                const v2f c2v = v2f{xid[r], xid[r + 1]} * v2f{factor, factor};
-                const v2f tot = v2f{st.lp[r], st.lp[r + 1]} + c2v;
-                const v2f pv = tot - c2v;
-                st.pv[r] = pv.x; st.pv[r + 1] = pv.y; st.pt[r] = tot.x; st.pt[r + 1] = tot.y;
-            } else {
-#pragma unroll
-                for (int q = r; q < r + 2 && q < S::NR; ++q) {
-                    const float c2v = xid[q] * factor;
-                    const float tot = st.lp[q] + c2v;
-                    st.pv[q] = tot - c2v;
-                    st.pt[q] = tot;
-                }
+            {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
+                const float c2v = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(pvr, min2, -min2))) * factor;
+                const float tot = st.lp[r] + c2v;
+                st.pv[r] = tot - c2v;                    // clamped where it is used (see above)
+                st.pt[r] = tot;
             }
-        }
+        });
         if (it > 0 && __ballot(static_cast<int>(syn) < 0) == 0ull) { success = true; --it; break; }
         hi = 50.0f;
         wave_sync();
         // information columns: tot = llr + sum of c2v in ascending check order
-        // (v_pk_add_f32 pairing of rounds / edges was measured: fewer VALU instructions, same time -- the
-        // loop is LDS-bound as much as VALU-bound)
-        static_for<0, (S::NC + 1) / 2>([&](auto R_) __attribute__((always_inline)) {
-            constexpr int r = 2 * decltype(R_)::value;
+        // (packed FP32 for the differences, the factor products and these sums was measured: fewer instructions, same time:
+        // a v_pk_* costs the issue time of the two scalar operations it replaces)
+        static_for<0, S::NC>([&](auto R_) __attribute__((always_inline)) {
+            constexpr int r = decltype(R_)::value;
             constexpr int DV = S::dv(r);
-            constexpr int DW = (r + 1 < S::NC) ? S::dv(r + 1) : 0;     // rounds are sorted by decreasing degree: DW <= DV
-            constexpr int off = I::col_off(r), off2 = off + DV;
-            static_assert(DW <= DV, "column rounds sorted by decreasing degree");
-            float ca[DV > 0 ? DV : 1], cb[DW > 0 ? DW : 1];
-            static_for<0, DV>([&](auto D_) __attribute__((always_inline)) { constexpr int d = decltype(D_)::value; ca[d] = lds_f(fast_addr<off + d>(st.cs, m0base)); });
-            static_for<0, DW>([&](auto D_) __attribute__((always_inline)) { constexpr int d = decltype(D_)::value; cb[d] = lds_f(fast_addr<off2 + d>(st.cs, m0base)); });
-            if constexpr (kPk && DW > 0) {
-                v2f tot = v2f{st.li[r], st.li[r + 1]};
+            constexpr int off = I::col_off(r);
+            if constexpr (DV > 0) {
+                float cv[DV];
 #pragma unroll
-                for (int d = 0; d < DW; ++d) tot = tot + v2f{ca[d], cb[d]};
-                float ta = tot.x;
+                for (int d = 0; d < DV; ++d) cv[d] = lds_f(st.cs[off + d]);
+                float tot = st.li[r];
 #pragma unroll
-                for (int d = DW; d < DV; ++d) ta = ta + ca[d];
-                lds_store_tid<4 * (I::tot_word + 64 * r)>(m0base, ta);
-                lds_store_tid<4 * (I::tot_word + 64 * (r + 1))>(m0base, tot.y);
-            } else {
-                if constexpr (DV > 0) {
-                    float ta = st.li[r];
-#pragma unroll
-                    for (int d = 0; d < DV; ++d) ta = ta + ca[d];
-                    lds_store_tid<4 * (I::tot_word + 64 * r)>(m0base, ta);
-                }
-                if constexpr (DW > 0) {
-                    float tb = st.li[r + 1];
-#pragma unroll
-                    for (int d = 0; d < DW; ++d) tb = tb + cb[d];
-                    lds_store_tid<4 * (I::tot_word + 64 * (r + 1))>(m0base, tb);
-                }
+                for (int d = 0; d < DV; ++d) tot = tot + cv[d];
+                lds_store_tid<4 * (I::tot_word + 64 * r)>(m0base, tot);
             }
         });
         wave_sync();
@@ -528,7 +380,8 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             constexpr int r = decltype(R_)::value;
             constexpr int off = I::row_off(r);
             uint32_t par = f2u(st.pt[r]);
-            static_for<0, S::ne(r)>([&](auto S_) __attribute__((always_inline)) { par ^= f2u(lds_f(fast_addr<off + decltype(S_)::value>(st.rv, m0base))); });
+#pragma unroll
+            for (int s = 0; s < S::ne(r); ++s) par ^= f2u(lds_f(st.rv[off + s]));
             syn |= par;
         });
         if (max_iter > 0 && __ballot(static_cast<int>(syn) < 0) == 0ull) { success = true; it = max_iter - 1; }
@@ -965,11 +818,13 @@ __global__ __launch_bounds__(256) void frame_validate_kernel(const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------ raw rows
-#ifndef RIA_EXP_ROWS_NCV
-#define RIA_EXP_ROWS_NCV (kCvRegs ? 1024 : S::kCv)
+// RIA_ROWS_NCV / RIA_ROWS_WAVES: build-time knobs of the core microbenchmark (tools/bench_core.py drives this kernel):
+// own-c2v words kept in registers and waves per SIMD of the raw-rows kernel
+#ifndef RIA_ROWS_NCV
+#define RIA_ROWS_NCV (kCvRegs ? 1024 : S::kCv)
 #endif
-#ifdef RIA_EXP_ROWS_WAVES
-#define RIA_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(RIA_EXP_ROWS_WAVES, RIA_EXP_ROWS_WAVES)))
+#ifdef RIA_ROWS_WAVES
+#define RIA_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(RIA_ROWS_WAVES, RIA_ROWS_WAVES)))
 #else
 #define RIA_ROWS_ATTR
 #endif
@@ -990,7 +845,7 @@ __global__ __launch_bounds__(64) RIA_ROWS_ATTR void fast_rows_kernel(FastCode c,
 #pragma unroll
         for (int r = 0; r < S::NR; ++r) { const uint32_t i = c.check_at[ln + 64 * r]; st.lp[r] = (i != 0xFFFFu) ? llr_canon(l[c.k + i]) : kIdleRowLlr; }
         bool ok;
-        int it = fast_decode<S, RIA_EXP_ROWS_NCV>(st, c, smem, factor, max_iter, lane, &ok);
+        int it = fast_decode<S, RIA_ROWS_NCV>(st, c, smem, factor, max_iter, lane, &ok);
         fast_pack(st, c, smem, out + static_cast<size_t>(cw) * nb, nb, lane);
         if (lane == 0) { ok_out[cw] = ok ? 1 : 0; iters_out[cw] = static_cast<uint16_t>(it); }
     }
