@@ -30,7 +30,10 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """Compile ria_amd/csrc/ria_gpu.hip -> ria_amd/lib/libria_gpu.so. Returns the library path."""
+    """Compile ria_amd/csrc/ria_gpu.hip -> ria_amd/lib/libria_gpu.so. Returns the library path.
+
+    Safe when several processes of one job (torchrun ranks) get here at once: one compiles under an exclusive file
+    lock, into a temporary name that is renamed into place; the others wait, re-check and load the finished library."""
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -39,10 +42,24 @@ def build(force=False, verbose=False):
             return LIB  # prebuilt library shipped with the snapshot, no compiler on this box
         raise RuntimeError("hipcc not found and no prebuilt libria_gpu.so")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "ria_gpu.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    import fcntl
+    with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "a") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB      # another process built it while this one waited
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp, os.path.join(CSRC, "ria_gpu.hip")]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd, cwd=CSRC)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
