@@ -501,7 +501,7 @@ __global__ void recovery_list_kernel(RecoveryArgs R) {
 template <class S>
 __global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned total = *R.n_list2;
+    const unsigned total = *R.n_list2 * 4u;
     if (blockIdx.x >= total) return;
     FastState<S> st;
     fast_load_tables(st, R.d.c, smem, threadIdx.x);
@@ -511,18 +511,18 @@ __global__ __launch_bounds__(64) void recovery_fill_kernel(RecoveryArgs R) {
         unsigned u = atomicAdd(R.next_fill, threadIdx.x == 0 ? 1u : 0u);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= total) break;
-        // one unit = one codeword: its soft bits are gathered from the frame once, then every factor it still lacks
-        const unsigned e = R.list2[u], fc = e >> 4;
+        // one unit = one (codeword, factor) decode the result table lacks: units of at most max_iter iterations balance
+        // the kernel's tail (a codeword that fails at every other factor used to be one unit of 4 x 80 iterations)
+        const unsigned e = R.list2[u >> 2], fc = e >> 4;
+        const int f = 1 + static_cast<int>(u & 3u);
+        if (!((e >> (f - 1)) & 1u)) continue;
         const FastCode& c = R.d.c;
         const int lane = threadIdx.x;
         fast_gather_llr(st, c, R.d.llr + static_cast<size_t>(fc >> 2) * R.d.llr_stride, R.d.gather, fc & 3, lane);
-        for (int f = 1; f <= 4; ++f) {
-            if (!((e >> (f - 1)) & 1u)) continue;
-            bool ok;
-            const int it = fast_decode<S>(st, c, smem, kFactors[f], c.max_iter, lane, &ok);
-            if (ok) fast_pack(st, c, smem, R.d.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw, c.bytes_per_cw, lane);
-            if (lane == 0) { R.d.res[fc].state[f] = ok ? 2 : 1; R.d.res[fc].iters[f] = static_cast<uint16_t>(it); }
-        }
+        bool ok;
+        const int it = fast_decode<S>(st, c, smem, kFactors[f], c.max_iter, lane, &ok);
+        if (ok) fast_pack(st, c, smem, R.d.res_bytes + (static_cast<size_t>(fc) * kNumFactors + f) * c.bytes_per_cw, c.bytes_per_cw, lane);
+        if (lane == 0) { R.d.res[fc].state[f] = ok ? 2 : 1; R.d.res[fc].iters[f] = static_cast<uint16_t>(it); }
     }
 }
 // one workgroup per flagged frame: compact copies of everything the host stage reads
