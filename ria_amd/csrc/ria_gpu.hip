@@ -952,20 +952,20 @@ int ria_gpu_zc_preamble(ria_gpu_handle h, int root, float* out_host, int max_n) 
 
 // forward or inverse 131072-point FFT of the active buffers of a chunk (see sync_kernels.hip.h)
 static void chirp_fft_forward(const ChirpArgs& A, int chunk, hipStream_t s, bool real_input, bool product) {
-    const dim3 g16(kChFft / 16 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
-    if (real_input) hipLaunchKernelGGL((chirp_fft_pass<4, 0, 1, false>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
-    else hipLaunchKernelGGL((chirp_fft_pass<4, 0, 2, false>), g16, blk, 0, s, A, static_cast<const float2*>(A.w2), A.w1);
-    hipLaunchKernelGGL((chirp_fft_pass<4, 4, 0, false>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
-    hipLaunchKernelGGL((chirp_fft_pass<4, 8, 0, false>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+    // 17 radix-2 stages as 6 + 6 + 5 register-resident butterfly networks (64 / 64 / 32 points per thread): three trips over the
+    // 1 MiB per buffer instead of the four of 4 + 4 + 4 + 5 (measured: 83 k -> 96 k preambles/s)
+    const dim3 g64(kChFft / 64 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
+    if (real_input) hipLaunchKernelGGL((chirp_fft_pass<6, 0, 1, false>), g64, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
+    else hipLaunchKernelGGL((chirp_fft_pass<6, 0, 2, false>), g64, blk, 0, s, A, static_cast<const float2*>(A.w2), A.w1);
+    hipLaunchKernelGGL((chirp_fft_pass<6, 6, 0, false>), g64, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
     if (product) hipLaunchKernelGGL((chirp_fft_pass<5, 12, 3, false>), g32, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
     else hipLaunchKernelGGL((chirp_fft_pass<5, 12, 0, false>), g32, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w1);
 }
 static void chirp_fft_inverse_mag(const ChirpArgs& A, int chunk, hipStream_t s) {
-    const dim3 g16(kChFft / 16 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
+    const dim3 g64(kChFft / 64 / 256, chunk), g32(kChFft / 32 / 256, chunk), blk(256);
     (void)hipMemsetAsync(A.best, 0, static_cast<size_t>(chunk) * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL((chirp_fft_pass<4, 0, 2, true>), g16, blk, 0, s, A, static_cast<const float2*>(A.w1), A.w2);
-    hipLaunchKernelGGL((chirp_fft_pass<4, 4, 0, true>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
-    hipLaunchKernelGGL((chirp_fft_pass<4, 8, 0, true>), g16, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
+    hipLaunchKernelGGL((chirp_fft_pass<6, 0, 2, true>), g64, blk, 0, s, A, static_cast<const float2*>(A.w1), A.w2);
+    hipLaunchKernelGGL((chirp_fft_pass<6, 6, 0, true>), g64, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
     hipLaunchKernelGGL((chirp_fft_pass<5, 12, 4, true>), g32, blk, 0, s, A, static_cast<const float2*>(nullptr), A.w2);
 }
 __global__ void chirp_template_stage_kernel(const float* tmpl, int down, float2* dst, ChirpBufState* st) {
