@@ -96,13 +96,16 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
         const int sym_index = (s < 2) ? s : (s == 2 ? kMcTrain : kMcTrain + 1 + (s - 3));
         const float* xs = x + sym_index * kMcSps;
         const float2* m = mix + c * kMcSps;
-        float sr = 0.0f, si = 0.0f;
+        // the two left-to-right sums advance together as one packed multiply and one packed add per sample (the IEEE
+        // operations of the halves; the build no longer SLP-packs, and here the packed form is the faster one: measured)
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        pk2 acc = {0.0f, 0.0f};
         for (int i = 0; i < kMcSps; ++i) {
             const float v = xs[i];
             const float2 w = m[i];
-            sr += v * w.x;
-            si += v * w.y;
+            acc = acc + pk2{v, v} * pk2{w.x, w.y};
         }
+        const float sr = acc.x, si = acc.y;
         Y[task] = make_float2(fdiv(sr, static_cast<float>(kMcSps)), fdiv(si, static_cast<float>(kMcSps)));
     }
     __syncthreads();
