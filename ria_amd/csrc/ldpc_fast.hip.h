@@ -523,6 +523,12 @@ __device__ inline void fast_unit(FastState<S>& st, const FastDecodeArgs& A, unsi
 // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own
 // L2, while the four codewords of a frame gather from the SAME 10 KB of interleaved soft bits; the map
 // below gives the four codewords of frame 8g+x the block ids 32g + 8cw + x, i.e. one XCD per frame.
+// The first decodes mostly converge within a few iterations: their time is input gathers and set-up latency, and a fourth
+// wave per SIMD (no own-c2v words in registers: 122 VGPRs at R1/2) hides more of it than the saved LDS re-reads are worth
+// (measured: decode stage -0.12 ms per 25 000 frames); the 80-iteration retry kernels are the other way round (Shape::kCv).
+#ifndef RIA_PRIMARY_NCV
+#define RIA_PRIMARY_NCV 0
+#endif
 template <class S>
 __global__ __launch_bounds__(64) void fast_primary_kernel(FastDecodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(64) void fast_primary_kernel(FastDecodeArgs A) {
     if (frame >= static_cast<unsigned>(A.n_frames)) return;
     FastState<S> st;
     fast_load_tables(st, A.c, smem, lane);
-    fast_unit(st, A, smem, 4u * frame + cw, 0, lane);
+    fast_unit<S, RIA_PRIMARY_NCV>(st, A, smem, 4u * frame + cw, 0, lane);
 }
 
 // per frame: every codeword at or after the first one whose first decode failed may need the other
