@@ -15,8 +15,7 @@
 //   * information columns are ordered by degree too; a padded column slot reads a word that holds
 //     +0.0f (x + 0.0f == x), idle lanes own private padding words, so nothing is masked;
 //   * sign/magnitude work is integer work on the float bit patterns: zeros are kept canonical (+0.0)
-//     so that "x < 0" IS the sign bit, |x| orders like the unsigned pattern, min1/min2 are
-//     v_min_u32 / v_med3_u32, the clamp is one v_med3_f32;
+//     so that "x < 0" IS the sign bit; magnitudes ride on the float source modifiers of v_min3 / v_med3 / v_min;
 //   * the retry cascade (frame_v2.cpp:1415-1546) is a second, persistent kernel over a device-side
 //     work list of (codeword, attempt) units.
 #pragma once
@@ -127,16 +126,17 @@ struct FastCode {
     const uint16_t* col_pos;    // [k]       sorted position of information column j
 };
 
-// Build-time experiments (measured on MI355X, C3 workload, decode kernels per 25k frames):
-//   kCvRegs   keep the row's own previous c2v in VGPRs instead of re-reading its LDS words: -24 LDS reads per
-//             iteration, +24 VGPRs -> the cascade kernel drops to 2 waves/SIMD: 20.4 -> 22.4 ms.  Off.
-//   kAddTid   ds_write_addtid_b32 for the lane-linear stores (M0 + offset + 4*lane, no address VGPR, half the
-//             store-path cycles): measured slower here (22.4 -> 23.4 ms with kCvRegs).  Off.
+// Build-time knobs:
+//   RIA_ADDTID   the lane-linear stores (c2v words, column totals) as ds_write_addtid_b32 (address = M0 + offset + 4*lane: no
+//                address VGPR, 2 store-path cycles per dword against 3 for the pairs of ds_write2st64_b32).  Slower in
+//                round 1 (when the loop was bound elsewhere), faster since the own-c2v words live in registers and the DS
+//                issue rate is what binds: 278 -> 273 CU-cycles per codeword-iteration, step -1 %.  On.
+//   RIA_CV_REGS  force every own-c2v word into registers whatever Shape::kCv says (experiments).
 #ifndef RIA_CV_REGS
 #define RIA_CV_REGS 0
 #endif
 #ifndef RIA_ADDTID
-#define RIA_ADDTID 0
+#define RIA_ADDTID 1
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr bool kCvRegs = RIA_CV_REGS != 0;
@@ -188,6 +188,33 @@ __device__ __forceinline__ void lds_store_tid(uint32_t base, float v) {
         return;
     }
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(v), "s"(base), "n"(OFF) : "memory", "m0");
+}
+// N stores STEP bytes apart behind ONE load of M0 (a row round's c2v words, the column totals)
+template <int N, int OFF, int STEP>
+__device__ __forceinline__ void lds_store_tid_n(uint32_t base, const float (&v)[N]) {
+    static_assert(N >= 1 && N <= 6 && OFF >= 0 && OFF + (N - 1) * STEP < 65536, "up to six 16-bit DS offsets");
+    if constexpr (!kAddTid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) *(lds_float_ptr)(uintptr_t)(base + static_cast<uint32_t>(threadIdx.x) * 4u + OFF + i * STEP) = v[i];
+        return;
+    }
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(v[0]), "s"(base), "n"(OFF) : "memory", "m0");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
+                     : : "v"(v[0]), "v"(v[1]), "s"(base), "n"(OFF), "n"(OFF + STEP) : "memory", "m0");
+    else if constexpr (N == 3)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%4\n\tds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6"
+                     : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(base), "n"(OFF), "n"(OFF + STEP), "n"(OFF + 2 * STEP) : "memory", "m0");
+    else if constexpr (N == 4)
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%5\n\tds_write_addtid_b32 %1 offset:%6\n\tds_write_addtid_b32 %2 offset:%7\n\tds_write_addtid_b32 %3 offset:%8"
+                     : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(base), "n"(OFF), "n"(OFF + STEP), "n"(OFF + 2 * STEP), "n"(OFF + 3 * STEP) : "memory", "m0");
+    else if constexpr (N == 5)
+        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%6\n\tds_write_addtid_b32 %1 offset:%7\n\tds_write_addtid_b32 %2 offset:%8\n\tds_write_addtid_b32 %3 offset:%9\n\tds_write_addtid_b32 %4 offset:%10"
+                     : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "s"(base), "n"(OFF), "n"(OFF + STEP), "n"(OFF + 2 * STEP), "n"(OFF + 3 * STEP), "n"(OFF + 4 * STEP) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%7\n\tds_write_addtid_b32 %1 offset:%8\n\tds_write_addtid_b32 %2 offset:%9\n\tds_write_addtid_b32 %3 offset:%10\n\tds_write_addtid_b32 %4 offset:%11\n\tds_write_addtid_b32 %5 offset:%12"
+                     : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "s"(base), "n"(OFF), "n"(OFF + STEP), "n"(OFF + 2 * STEP), "n"(OFF + 3 * STEP), "n"(OFF + 4 * STEP), "n"(OFF + 5 * STEP) : "memory", "m0");
 }
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
@@ -339,11 +366,13 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
             // bits(min1) ^ bits(min2) ^ row-sign swaps the magnitude to the other candidate and turns the edge's own
             // sign into the product of the others.  (sign * min_abs) * factor is then the reference's own order.
             const uint32_t dS = bfi(kAbs, f2u(min1) ^ f2u(min2), sgn);
+            float o[NE];
+#pragma unroll
+            for (int s = 0; s < NE; ++s) o[s] = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(v[s], min2, -min2))) * factor;
+            lds_store_tid_n<NE, 256 * off, 256>(m0base, o);
             static_for<0, NE>([&](auto S_) __attribute__((always_inline)) {
                 constexpr int s = decltype(S_)::value;
-                const float o = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(v[s], min2, -min2))) * factor;
-                lds_store_tid<256 * (off + s)>(m0base, o);
-                if constexpr (off + s < NCV) st.cv[off + s] = o;
+                if constexpr (off + s < NCV) st.cv[off + s] = o[s];
             });
             {   // identity column: degree 1, total = llr + c2v, v2c = clamp(total - c2v)
                 const float c2v = u2f(dS ^ f2u(__builtin_amdgcn_fmed3f(pvr, min2, -min2))) * factor;
@@ -358,19 +387,27 @@ __device__ inline int fast_decode(FastState<S>& st, const FastCode& c, unsigned 
         // information columns: tot = llr + sum of c2v in ascending check order
         // (packed FP32 for the differences, the factor products and these sums was measured: fewer instructions, same time:
         // a v_pk_* costs the issue time of the two scalar operations it replaces)
-        static_for<0, S::NC>([&](auto R_) __attribute__((always_inline)) {
+        // (columns of degree 0 only exist in the last rounds: their totals stay at the channel value written at the start)
+        constexpr int NCE = []() constexpr { int n = 0; for (int r = 0; r < S::NC; ++r) if (S::dv(r) > 0) n = r + 1; return n; }();
+        float totv[NCE > 0 ? NCE : 1];
+        static_for<0, NCE>([&](auto R_) __attribute__((always_inline)) {
             constexpr int r = decltype(R_)::value;
             constexpr int DV = S::dv(r);
             constexpr int off = I::col_off(r);
-            if constexpr (DV > 0) {
-                float cv[DV];
+            float cv[DV > 0 ? DV : 1];
 #pragma unroll
-                for (int d = 0; d < DV; ++d) cv[d] = lds_f(st.cs[off + d]);
-                float tot = st.li[r];
+            for (int d = 0; d < DV; ++d) cv[d] = lds_f(st.cs[off + d]);
+            float tot = st.li[r];
 #pragma unroll
-                for (int d = 0; d < DV; ++d) tot = tot + cv[d];
-                lds_store_tid<4 * (I::tot_word + 64 * r)>(m0base, tot);
-            }
+            for (int d = 0; d < DV; ++d) tot = tot + cv[d];
+            totv[r] = tot;
+        });
+        static_for<0, (NCE + 5) / 6>([&](auto G_) __attribute__((always_inline)) {     // groups of up to six stores behind one M0 load
+            constexpr int g0 = 6 * decltype(G_)::value, gn = (NCE - g0 < 6) ? NCE - g0 : 6;
+            float tv[gn];
+#pragma unroll
+            for (int i = 0; i < gn; ++i) tv[i] = totv[g0 + i];
+            lds_store_tid_n<gn, 4 * (I::tot_word + 64 * g0), 256>(m0base, tv);
         });
         wave_sync();
     }
