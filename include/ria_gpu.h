@@ -363,6 +363,26 @@ int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32
 int ria_gpu_channel_exact_seeded_batch(ria_gpu_handle h, int kind, float snr_db, const uint32_t* seeds_dev, float* samples_dev,
                                        int64_t stride, int frame_samples, int n_frames, void* stream);
 
+/* The same channel object with its CFO impairment (hf_channel.hpp:47-51 Config::cfo_hz / random_cfo_max_hz): frame f =
+ * sim::WattersonChannel(cfg{cfo_hz = cfo_hz_dev[f] (NULL: 0), random_cfo_max_hz}, seeds_dev[f]).process(frame f).
+ * random_cfo_max_hz > 0 replaces the configured offset by the constructor's uniform draw from the frame's own generator
+ * (:97-102; it takes the first random word, so every later noise value shifts); the noise / fading pass is followed by
+ * applyCFO (:172-174, :182-241: mix to baseband at 1500 Hz, 48-sample running-sum average, rotate, mix back) whenever
+ * |offset| > 0.001 Hz and the frame has at least 256 samples.  actual_cfo_out_dev (nullable, n_frames floats) =
+ * getActualCFO().  Bit-identical output. */
+int ria_gpu_channel_exact_cfo_batch(ria_gpu_handle h, int kind, float snr_db, const uint32_t* seeds_dev, const float* cfo_hz_dev,
+                                    float random_cfo_max_hz, float* actual_cfo_out_dev, float* samples_dev, int64_t stride,
+                                    int frame_samples, int n_frames, void* stream);
+
+/* The simulator's transmitter frequency offset: SimulatedChannel::applyTxCFO(samples, phase_acc)
+ * (tools/cli_simulator.cpp:298-341; BASELINE.json config 4's "+-50 Hz CFO" by analytic-signal rotation) for n_buffers
+ * transmissions of n_samples each (buffer b at samples_dev + b*stride, result at out_dev + b*out_stride, not in place):
+ * FFT of the next power of two, frequency-domain Hilbert, inverse FFT, rotation by cfo_hz_dev[b] with the wrapped float
+ * phase accumulator phase_inout_dev[b] (NULL: starts at 0, not returned), real part.  |cfo| < 0.001 Hz copies the
+ * samples and leaves the accumulator alone, as the reference does.  n_samples <= 131072.  Bit-identical output. */
+int ria_gpu_tx_cfo_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int n_samples, int n_buffers,
+                         const float* cfo_hz_dev, float* phase_inout_dev, float* out_dev, int64_t out_stride, void* stream);
+
 /* ---- burst interleaver (fec::BurstInterleaver, src/fec/burst_interleaver.cpp:8-78) -----------------
  * A burst of N physical frames carries N logical frames byte-interleaved: physical[(N*b+f)/324][(N*b+f)%324] =
  * logical[f][b].  deinterleave works on the soft bits (8 per byte) of n_groups bursts of N frames each:

@@ -335,6 +335,59 @@ def chirp_fixture(R):
     return rec
 
 
+# ---- config 4: the two CFO impairments and the acquisition grid (recorded from the reference)
+TXCFO_CASES = [(2512, -50.0, 0.0), (2512, 25.0, 1.25), (2512, 0.0005, 0.5), (300, 13.7, -3.0), (4096, -25.0, 0.0), (1, 10.0, 0.25),
+               (2, -10.0, 0.0), (63, 50.0, 2.0), (5000, 50.0, -1.0)]
+CHANCFO_CASES = [(0, 25.0, 0.0), (0, -50.0, 0.0), (1, 10.5, 0.0), (2, 50.0, 0.0), (3, -25.0, 0.0), (4, 0.0, 30.0), (0, 5.0, 50.0),
+                 (2, 0.0005, 0.0), (0, 0.0, 0.0)]          # (preset, cfo_hz, random_cfo_max_hz)
+ACQ_GRID = [(c, s) for c in (-50.0, -25.0, 0.0, 25.0, 50.0) for s in (-10.0, -5.0, 0.0, 5.0, 10.0)]
+ACQ_KINDS = (("zc", 4512, 2000), ("chirp", 120000, 62400))
+ACQ_PER_POINT = 2
+ACQ_SEED = 20261005
+
+
+def txcfo_input(R, n, idx):
+    pre = R.zc_generate(5)
+    if n <= len(pre):
+        return pre[:n].copy()
+    return (np.random.default_rng(7100 + idx).standard_normal(n) * 0.3).astype(np.float32)
+
+
+def cfo_fixture(R):
+    """applyTxCFO outputs, WattersonChannel outputs with cfo_hz / random_cfo_max_hz, and the config-4 grid: per grid
+    point and kind ACQ_PER_POINT buffers built from the recipe of ria_amd/sweep.py (acq_recipe / make_acq_buffers ==
+    pyoracle.acq_buffer), their checksums and the detectors' result records (ZC with known_cfo = the grid CFO)."""
+    import zlib
+    sys.path.insert(0, os.path.dirname(po.HERE))
+    from ria_amd.sweep import acq_recipe
+    rec = {"txcfo_cases": np.array(TXCFO_CASES, np.float64), "chancfo_cases": np.array(CHANCFO_CASES, np.float64)}
+    for i, (n, cfo, ph) in enumerate(TXCFO_CASES):
+        y, p1 = R.apply_tx_cfo(txcfo_input(R, n, i), cfo, ph)
+        rec[f"txcfo_y_{i}"] = y
+        rec[f"txcfo_phase_{i}"] = np.float32(p1)
+    x = np.load(os.path.join(OUT, "channel_vectors.npz"))["x"]          # 6000 samples, 200 leading zeros
+    for i, (kind, cfo, rmax) in enumerate(CHANCFO_CASES):
+        y, actual = R.channel_cfo(kind, 15.0, 177 + i, x, cfo, rmax)
+        rec[f"chancfo_y_{i}"] = y
+        rec[f"chancfo_actual_{i}"] = np.float32(actual)
+    y, _ = R.channel_cfo(0, 10.0, 5, x[:255], 25.0, 0.0)                # below applyCFO's 256-sample gate
+    rec["chancfo_short"] = y
+    pres = {"zc": R.zc_generate(5), "chirp": R.chirp_generate()}
+    crc, res = {"zc": [], "chirp": []}, {"zc": [], "chirp": []}
+    for gi, (cfo, snr) in enumerate(ACQ_GRID):
+        for ki, (kind, buf_len, max_off) in enumerate(ACQ_KINDS):
+            offs, seeds = acq_recipe(ACQ_SEED, gi, ki, np.arange(ACQ_PER_POINT), max_off)
+            for q in range(ACQ_PER_POINT):
+                buf = po.acq_buffer(R, pres[kind], buf_len, int(offs[q]), int(seeds[q]), snr, cfo, "tx")
+                crc[kind].append(zlib.crc32(buf.tobytes()))
+                res[kind].append(R.zc_detect(buf, 0.3, 15, cfo) if kind == "zc" else R.chirp_detect(buf, 0.15))
+    for kind in ("zc", "chirp"):
+        rec[f"acq_{kind}_crc"] = np.array(crc[kind], np.uint32)
+        rec[f"acq_{kind}_results"] = np.stack(res[kind])
+    rec["acq_seed"] = np.int64(ACQ_SEED)
+    return rec
+
+
 def main():
     if not po.Ref.available():
         print("needs oracle/_ref/libria_ref.so (make -C oracle ref)")
@@ -384,6 +437,9 @@ def main():
         return 0
     if only == "robust":
         np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
+        return 0
+    if only == "cfo":
+        np.savez_compressed(os.path.join(OUT, "cfo_impairment.npz"), **cfo_fixture(R))
         return 0
     if only == "burst":
         np.savez_compressed(os.path.join(OUT, "burst_chain.npz"), **burst_fixture(R, O))
@@ -459,6 +515,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "burst_interleaver.npz"), **burst_interleaver_fixture(R))
     np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
     np.savez_compressed(os.path.join(OUT, "harq_trials.npz"), **harq_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "cfo_impairment.npz"), **cfo_fixture(R))
     print("done ->", OUT)
     return 0
 

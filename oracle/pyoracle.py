@@ -66,6 +66,19 @@ def build_oracle():
     return so
 
 
+def acq_buffer(checker, pre, buf_len, off, seed, snr_db, cfo_hz, cfo_model="tx"):
+    """One config-4 acquisition buffer on the CPU, from the same recipe ria_amd.sweep.make_acq_buffers follows on the
+    device (checker: Oracle or Ref): preamble -> [applyTxCFO] -> placed at `off` in silence -> AWGN WattersonChannel
+    (mt19937 `seed`), with Config::cfo_hz instead of the transmitter offset for cfo_model "watterson"."""
+    buf = np.zeros(buf_len, np.float32)
+    if cfo_model == "tx":
+        seg, _ = checker.apply_tx_cfo(pre, cfo_hz)
+        buf[off:off + len(pre)] = seg
+        return checker.channel(0, snr_db, int(seed), buf)
+    buf[off:off + len(pre)] = pre
+    return checker.channel_cfo(0, snr_db, int(seed), buf, cfo_hz)[0]
+
+
 class Oracle:
     """Our C restatement (oracle/ria_oracle.c)."""
 
@@ -80,6 +93,8 @@ class Oracle:
         L.ro_burst_deinterleave.argtypes = [C.c_int, _f, C.c_int, _f]
         L.ro_burst_deinterleave.restype = None
         L.ro_channel.argtypes = [C.c_int, C.c_float, C.c_uint32, _f, C.c_int, _f]
+        L.ro_channel_cfo.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_float, C.c_float, _f, C.c_int, _f, _f]
+        L.ro_apply_tx_cfo.argtypes = [_f, C.c_int, C.c_float, _f, _f]
         L.ro_ldpc_decode.argtypes = [C.POINTER(Ldpc), _f, C.c_int, C.c_int, C.c_float, _u8, _i]
         L.ro_decode_fixed_frame.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8, _u8, _i, _i]
         L.ro_crc16.restype = C.c_uint16
@@ -208,6 +223,22 @@ class Oracle:
         self.lib.ro_channel(kind, snr_db, seed, fp(x), len(x), fp(y))
         return y
 
+    def channel_cfo(self, kind, snr_db, seed, x, cfo_hz=0.0, random_cfo_max_hz=0.0):
+        """WattersonChannel with Config::cfo_hz / random_cfo_max_hz -> (samples, getActualCFO())"""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        a = np.zeros(1, np.float32)
+        self.lib.ro_channel_cfo(kind, snr_db, seed, cfo_hz, random_cfo_max_hz, fp(x), len(x), fp(y), fp(a))
+        return y, float(a[0])
+
+    def apply_tx_cfo(self, x, cfo_hz, phase=0.0):
+        """SimulatedChannel::applyTxCFO -> (samples, phase accumulator after)"""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        ph = np.array([phase], np.float32)
+        self.lib.ro_apply_tx_cfo(fp(x), len(x), cfo_hz, fp(ph), fp(y))
+        return y, float(ph[0])
+
     def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0, burst_marker=False):
         g = self.geom(mod, rate)
         samples = np.ascontiguousarray(samples, np.float32)
@@ -311,7 +342,45 @@ class Ref:
         L.ref_harq_trials.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _u8, _u32, C.c_int, C.c_int, _i, _u32, _u32, _i, _u8, _f]
         L.ref_burst_interleave.argtypes = [C.c_int, _u8, _u8]
         L.ref_burst_deinterleave.argtypes = [C.c_int, _f, _f]
+        L.ref_channel_cfo.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_float, C.c_float, _f, C.c_int, _f, _f]
+        L.ref_apply_tx_cfo.argtypes = [_f, C.c_int, C.c_float, _f, _f]
+        L.ref_rx_open.argtypes = [C.c_int, C.c_int]
+        L.ref_rx_open.restype = C.c_void_p
+        L.ref_rx_close.argtypes = [C.c_void_p]
+        L.ref_rx_close.restype = None
+        L.ref_rx_frame.argtypes = [C.c_void_p, _f, C.c_int, C.c_float, _u8, _u8, _f, C.c_int]
         L.ref_quiet()
+
+    def channel_cfo(self, kind, snr_db, seed, x, cfo_hz=0.0, random_cfo_max_hz=0.0):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        a = np.zeros(1, np.float32)
+        self.lib.ref_channel_cfo(kind, snr_db, seed, cfo_hz, random_cfo_max_hz, fp(x), len(x), fp(y), fp(a))
+        return y, float(a[0])
+
+    def apply_tx_cfo(self, x, cfo_hz, phase=0.0):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        ph = np.array([phase], np.float32)
+        self.lib.ref_apply_tx_cfo(fp(x), len(x), cfo_hz, fp(ph), fp(y))
+        return y, float(ph[0])
+
+    def rx_open(self, mod, rate):
+        """One kept OFDMChirpWaveform (configured once): the per-thread object of the CPU throughput baseline"""
+        return self.lib.ref_rx_open(mod, rate)
+
+    def rx_close(self, h):
+        self.lib.ref_rx_close(h)
+
+    def rx_frame(self, h, samples, cfo_hz=0.0, want_llr=False):
+        """reset -> setFrequencyOffset -> process -> getSoftBits -> decodeFixedFrame on the kept object
+        -> (codewords decoded or -1, data, ok[, llr])"""
+        x = np.ascontiguousarray(samples, np.float32)
+        data = np.zeros(4 * 68, np.uint8)
+        ok = np.zeros(4, np.uint8)
+        llr = np.zeros(8 * NCAR * 64, np.float32) if want_llr else None
+        n = self.lib.ref_rx_frame(h, fp(x), len(x), cfo_hz, up(data), up(ok), fp(llr) if want_llr else None, len(llr) if want_llr else 0)
+        return (n, data, ok, llr) if want_llr else (n, data, ok)
 
     def cox_search(self, samples, threshold=0.8, noise_floor=0.0, mod=QAM16, rate=R1_2):
         x = np.ascontiguousarray(samples, np.float32)

@@ -162,6 +162,71 @@ int ref_channel(int kind, float snr_db, uint32_t seed, const float* in, int n, f
     return n;
 }
 
+// The same channel with the reference's CFO impairment: Config::cfo_hz / random_cfo_max_hz (hf_channel.hpp:47-51),
+// the CFO draw of the constructor (:97-102, taken from rng_ BEFORE any noise is drawn) and applyCFO (:182-241: mix to
+// baseband at 1500 Hz, 48-tap moving average, rotate, mix back).  actual_cfo_out = getActualCFO().
+int ref_channel_cfo(int kind, float snr_db, uint32_t seed, float cfo_hz, float random_cfo_max_hz, const float* in, int n, float* out,
+                    float* actual_cfo_out) {
+    ref_quiet();
+    sim::WattersonChannel::Config c;
+    switch (kind) {
+        case 0: c = sim::itu_r_f1487::awgn(snr_db); break;
+        case 1: c = sim::itu_r_f1487::good(snr_db); break;
+        case 2: c = sim::itu_r_f1487::moderate(snr_db); break;
+        case 3: c = sim::itu_r_f1487::poor(snr_db); break;
+        default: c = sim::itu_r_f1487::flutter(snr_db); break;
+    }
+    c.cfo_hz = cfo_hz;
+    c.random_cfo_max_hz = random_cfo_max_hz;
+    sim::WattersonChannel ch(c, seed);
+    Samples o = ch.process(SampleSpan(in, n));
+    std::memcpy(out, o.data(), n * sizeof(float));
+    if (actual_cfo_out) *actual_cfo_out = ch.getActualCFO();
+    return n;
+}
+
+// ---------------------------------------------------------------- RX, one kept object per caller thread
+// The CPU throughput baseline ("one instance per std::thread"): ONE OFDMChirpWaveform configured once,
+// reset() before every frame as StreamingDecoder does (streaming_decoder.cpp:723), then setFrequencyOffset -> process ->
+// getSoftBits -> v2::decodeFixedFrame.  ref_rx_process above builds and configures a new object per call (two
+// initComponents()), which is right for fixtures but inflates a per-frame time.
+struct RefRx {
+    std::unique_ptr<OFDMChirpWaveform> rx;
+    CodeRate rate;
+    int bps;
+};
+void* ref_rx_open(int mod, int rate) {
+    ref_quiet();
+    auto* h = new RefRx();
+    ModemConfig cfg = named_config(mod, rate);
+    h->rx = std::make_unique<OFDMChirpWaveform>(cfg);
+    h->rx->configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    h->rate = static_cast<CodeRate>(rate);
+    const int pilots = (cfg.num_carriers + h->rx->config_.pilot_spacing - 1) / h->rx->config_.pilot_spacing;
+    h->bps = (cfg.num_carriers - pilots) * static_cast<int>(getBitsPerSymbol(static_cast<Modulation>(mod)));
+    return h;
+}
+void ref_rx_close(void* hv) { delete static_cast<RefRx*>(hv); }
+// returns the number of codewords decoded (0..4), -1 if process() produced no soft bits; llr_out nullable
+int ref_rx_frame(void* hv, const float* samples, int n, float cfo_hz, uint8_t* data_out, uint8_t* ok_out, float* llr_out, int max_llr) {
+    auto* h = static_cast<RefRx*>(hv);
+    h->rx->reset();
+    h->rx->setFrequencyOffset(cfo_hz);
+    bool ok = h->rx->process(SampleSpan(samples, n));
+    std::vector<float> soft = h->rx->getSoftBits();
+    if (llr_out) std::memcpy(llr_out, soft.data(), std::min<size_t>(soft.size(), max_llr) * sizeof(float));
+    if (!ok || soft.size() < 2592) return -1;
+    auto st = protocol::v2::decodeFixedFrame(soft, h->rate, true, h->bps);
+    size_t bpc = protocol::v2::getBytesPerCodeword(h->rate);
+    int good = 0;
+    for (int cw = 0; cw < 4; ++cw) {
+        ok_out[cw] = st.decoded[cw] ? 1 : 0;
+        std::memset(data_out + cw * bpc, 0, bpc);
+        if (st.decoded[cw] && st.data[cw].size() >= bpc) { std::memcpy(data_out + cw * bpc, st.data[cw].data(), bpc); ++good; }
+    }
+    return good;
+}
+
 // ---------------------------------------------------------------- RX demod
 // aux_out[0..7] = {snr_db, cfo_hz_out, fading_index, noise_variance, lts_phase_slope,
 //                  estimated_snr_linear, freq_correction_phase, snr_symbol_count}

@@ -547,8 +547,50 @@ int ro_modulate(const ro_geom* g, const uint8_t* coded, int n_coded, float* samp
 }
 
 /* ------------------------------------------------------------------ channel */
+/* WattersonChannel::applyCFO (hf_channel.hpp:182-241): mix to baseband at 1500 Hz, 48-tap running-sum moving average,
+ * rotate by the CFO phase, mix back.  The mixer phase is 2*pi*fc*t evaluated in double and rounded to float; the running
+ * sums add the new and subtract the old sample in float; the CFO phase only wraps downwards (positive offsets). */
+static void ro_apply_cfo(float* s, int n, float phase_inc) {
+    if (n < 256) return;
+    const float fc = 1500.0f, fs = (float)48000u;
+    float* Ib = (float*)malloc(sizeof(float) * (size_t)n); float* Qb = (float*)malloc(sizeof(float) * (size_t)n);
+    float* If = (float*)malloc(sizeof(float) * (size_t)n); float* Qf = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float t = (float)i / fs;
+        float mp = (float)(2.0f * M_PI * (double)fc * (double)t);
+        Ib[i] = s[i] * cosf(mp);
+        Qb[i] = s[i] * sinf(mp);
+    }
+    const int win = 48;
+    float Is = 0, Qs = 0;
+    for (int i = 0; i < n; ++i) {
+        Is += Ib[i]; Qs += Qb[i];
+        if (i >= win) { Is -= Ib[i - win]; Qs -= Qb[i - win]; }
+        int m = (i + 1 < win) ? i + 1 : win;
+        If[i] = Is / (float)m;      /* float / size_t: the count is converted to float */
+        Qf[i] = Qs / (float)m;
+    }
+    float phase = 0.0f;             /* cfo_phase_ of a fresh channel object */
+    for (int i = 0; i < n; ++i) {
+        float t = (float)i / fs;
+        float mp = (float)(2.0f * M_PI * (double)fc * (double)t);
+        float cc = cosf(phase), cs = sinf(phase);
+        float Ic = If[i] * cc - Qf[i] * cs;
+        float Qc = If[i] * cs + Qf[i] * cc;
+        s[i] = 2.0f * (Ic * cosf(mp) - Qc * sinf(mp));
+        phase += phase_inc;
+        if ((double)phase > 2.0f * M_PI) phase = (float)((double)phase - 2.0f * M_PI);
+    }
+    free(Ib); free(Qb); free(If); free(Qf);
+}
+
 int ro_channel(int kind, float snr_db, uint32_t seed, const float* in, int n, float* out) {
-    /* hf_channel.hpp:68-103 ctor, :107-177 process, :267-284 updateFading, presets :411-488 */
+    return ro_channel_cfo(kind, snr_db, seed, 0.0f, 0.0f, in, n, out, NULL);
+}
+
+int ro_channel_cfo(int kind, float snr_db, uint32_t seed, float cfo_hz, float random_cfo_max_hz, const float* in, int n, float* out,
+                   float* actual_cfo_out) {
+    /* hf_channel.hpp:68-103 ctor, :107-177 process, :267-284 updateFading, :182-241 applyCFO, presets :411-488 */
     float delay_ms = 0, doppler = 0, g1 = 1.0f, g2 = 0.0f;
     int fading = 1, multipath = 1;
     switch (kind) {
@@ -561,6 +603,12 @@ int ro_channel(int kind, float snr_db, uint32_t seed, const float* in, int n, fl
     ro_mt rng;
     ro_mt_seed(&rng, seed);
     ro_normal gs = { 0, 0 };
+    /* CFO of this channel object (:97-102): a uniform_real_distribution<float>(-max, max) draw from the SAME generator,
+     * before any noise is drawn (libstdc++: (b - a) * generate_canonical<float,24>(rng) + a) */
+    float actual_cfo = cfo_hz;
+    if (random_cfo_max_hz > 0.0f) actual_cfo = (random_cfo_max_hz - (-random_cfo_max_hz)) * ro_canonical(&rng) + (-random_cfo_max_hz);
+    float cfo_inc = (float)(2.0f * M_PI * (double)actual_cfo / (double)48000u);
+    if (actual_cfo_out) *actual_cfo_out = actual_cfo;
     int delay = (int)(delay_ms * 48000 / 1000.0f);
     float norm_dopp = doppler / 48000;
     float alpha = (float)(1.0f - exp(-2.0f * M_PI * (double)norm_dopp));
@@ -603,6 +651,7 @@ int ro_channel(int kind, float snr_db, uint32_t seed, const float* in, int n, fl
         out[i] = o;
     }
     free(dl);
+    if (fabsf(actual_cfo) > 0.001f) ro_apply_cfo(out, n, cfo_inc);   /* :172-174 (cfo_enabled defaults to true) */
     return n;
 }
 

@@ -81,6 +81,10 @@ int ro_modulate(const ro_geom* g, const uint8_t* coded, int n_coded, float* samp
 
 /* ---- channel (src/sim/hf_channel.hpp) kind: 0 awgn 1 good 2 moderate 3 poor 4 flutter */
 int ro_channel(int kind, float snr_db, uint32_t seed, const float* in, int n, float* out);
+/* the same with Config::cfo_hz / random_cfo_max_hz: the constructor's CFO draw (hf_channel.hpp:97-102) and applyCFO
+ * (:182-241) after the noise; actual_cfo_out (nullable) = getActualCFO() */
+int ro_channel_cfo(int kind, float snr_db, uint32_t seed, float cfo_hz, float random_cfo_max_hz, const float* in, int n, float* out,
+                   float* actual_cfo_out);
 
 /* ---- RX demod (src/ofdm/demodulator.cpp, channel_equalizer.cpp, soft_demap.hpp) */
 typedef struct ro_rx_aux {
@@ -124,6 +128,9 @@ int ro_mcdpsk_demod(int nc, int bps, int spreading, const float* samples, int n,
                     float* llr_out, int max_llr, float* aux4);
 /* OFDMChirpWaveform::detectDataSync (LTS light sync); out4 = {detected, start_sample, correlation, burst_interleaved} */
 int ro_detect_data_sync(const float* x, int n, float known_cfo_hz, float threshold, float* out4);
+/* SimulatedChannel::applyTxCFO (tools/cli_simulator.cpp:298-341): the simulator's transmitter frequency offset - FFT of
+ * the next power of two, frequency-domain Hilbert, inverse FFT, rotation by a wrapped float phase (in/out), real part */
+int ro_apply_tx_cfo(const float* in, int n, float cfo_hz, float* phase_inout, float* out);
 /* fec::ChaseCache::store arithmetic for one codeword slot (src/fec/chase_cache.cpp:27-88) */
 int ro_chase_store(float* existing, int* combine_count, int decoded, const float* soft);
 

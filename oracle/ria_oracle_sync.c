@@ -870,3 +870,68 @@ int ro_detect_data_sync(const float* x, int n, float known_cfo_hz, float thresho
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SimulatedChannel::applyTxCFO (tools/cli_simulator.cpp:298-341): analytic-signal frequency shift of one transmission.
+ * FFT = ultra::FFT of size 2^ceil(log2 n) (src/dsp/fft.cpp:83-128: twiddle k = (cosf, sinf)((float)(-2*pi*k/N)), radix-2
+ * DIT, inverse = conjugated twiddles then * (1/N)). */
+static void tx_cfo_fft(scf* data, int size, const scf* tw, int inverse) {
+    int j = 0;
+    for (int i = 0; i < size - 1; ++i) {
+        if (i < j) { scf t = data[i]; data[i] = data[j]; data[j] = t; }
+        int k = size / 2;
+        while (k <= j) { j -= k; k /= 2; }
+        j += k;
+    }
+    for (int len = 2; len <= size; len *= 2) {
+        int half = len / 2, step = size / len;
+        for (int i = 0; i < size; i += len)
+            for (int k = 0; k < half; ++k) {
+                scf w = tw[k * step];
+                if (inverse) w.im = -w.im;
+                scf d = data[i + k + half], a = data[i + k], t;
+                t.re = w.re * d.re - w.im * d.im;
+                t.im = w.re * d.im + w.im * d.re;
+                data[i + k + half].re = a.re - t.re; data[i + k + half].im = a.im - t.im;
+                data[i + k].re = a.re + t.re; data[i + k].im = a.im + t.im;
+            }
+    }
+    if (inverse) {
+        float scale = 1.0f / (float)size;
+        for (int i = 0; i < size; ++i) { data[i].re *= scale; data[i].im *= scale; }
+    }
+}
+int ro_apply_tx_cfo(const float* in, int n, float cfo_hz, float* phase_inout, float* out) {
+    if (fabsf(cfo_hz) < 0.001f || n <= 0) {                              /* :299-301 */
+        if (n > 0 && out != in) memcpy(out, in, sizeof(float) * (size_t)n);
+        return n;
+    }
+    int size = 1;
+    while (size < n) size <<= 1;                                         /* :304-305 */
+    scf* tw = (scf*)malloc(sizeof(scf) * (size_t)(size / 2 + 1));
+    for (int k = 0; k < size / 2; ++k) {
+        float angle = (float)(-2.0f * M_PI * (double)k / (double)size);
+        tw[k].re = cosf(angle); tw[k].im = sinf(angle);
+    }
+    scf* f = (scf*)calloc((size_t)size, sizeof(scf));
+    for (int i = 0; i < n; ++i) f[i].re = in[i];
+    tx_cfo_fft(f, size, tw, 0);
+    if (size >= 2) {                                                     /* :318-325 */
+        for (int i = 1; i < size / 2; ++i) { f[i].re *= 2.0f; f[i].im *= 2.0f; }
+        for (int i = size / 2 + 1; i < size; ++i) { f[i].re = 0.0f; f[i].im = 0.0f; }
+    }
+    tx_cfo_fft(f, size, tw, 1);
+    const float pi_f = (float)M_PI;
+    const float phase_inc = 2.0f * pi_f * cfo_hz / 48000.0f;             /* all float (:330) */
+    float phase = phase_inout ? *phase_inout : 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float c = cosf(phase), s = sinf(phase);
+        out[i] = f[i].re * c - f[i].im * s;                              /* real(analytic * rot) */
+        phase += phase_inc;
+        if (phase > pi_f) phase -= 2.0f * pi_f;
+        else if (phase < -pi_f) phase += 2.0f * pi_f;
+    }
+    if (phase_inout) *phase_inout = phase;
+    free(f); free(tw);
+    return n;
+}

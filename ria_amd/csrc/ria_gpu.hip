@@ -29,6 +29,7 @@
 #include "sync_kernels.hip.h"
 #include "mcdpsk_kernels.hip.h"
 #include "cox_kernels.hip.h"
+#include "cfo_kernels.hip.h"
 
 using namespace ria;
 
@@ -49,6 +50,8 @@ struct ria_gpu {
     void* d_ch_tw = nullptr; void* d_ch_tmpl = nullptr; void* d_ch_tmpl_fft = nullptr; float ch_energy[2] = {0, 0};
     void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
     int ch_chunk = 0, ch_outer = 0;
+    // transmitter-CFO impairment (cfo_kernels.hip.h): two complex arrays + the phase table, grown on demand
+    void* d_txcfo_ws = nullptr; size_t txcfo_ws_bytes = 0;
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
     std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
@@ -405,7 +408,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
-    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws}) if (p) (void)hipFree(p);
+    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws, h->d_txcfo_ws}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c, (void*)h->d_overflow}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
@@ -904,6 +907,20 @@ int ria_gpu_channel_exact_seeded_batch(ria_gpu_handle h, int kind, float snr_db,
     return RIA_OK;
 }
 
+int ria_gpu_channel_exact_cfo_batch(ria_gpu_handle h, int kind, float snr_db, const uint32_t* seeds_dev, const float* cfo_hz_dev,
+                                    float random_cfo_max_hz, float* actual_cfo_out_dev, float* samples_dev, int64_t stride,
+                                    int frame_samples, int n_frames, void* stream) {
+    if (!h || n_frames < 0 || kind < 0 || kind > 4 || frame_samples < 0 || stride < frame_samples || !(random_cfo_max_hz >= 0.0f))
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_cfo_batch: bad argument");
+    if (n_frames == 0 || frame_samples == 0) return RIA_OK;
+    if (!samples_dev || !seeds_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_cfo_batch: null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_channel_exact(kind, snr_db, 0u, 0u, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), seeds_dev,
+                         cfo_hz_dev, 0.0f, random_cfo_max_hz, actual_cfo_out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ debug
 __global__ void debug_math_kernel(int op, const float* a, const float* b, int n, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -997,9 +1014,9 @@ static int chirp_prepare(ria_gpu_handle h, int chunk, int outer, hipStream_t s) 
         C_TRY(hipMalloc(&h->d_ch_st, static_cast<size_t>(outer) * sizeof(ChirpBufState)));
         h->ch_outer = outer;
     }
-    if (!h->d_ch_tw) {
+    if (!h->d_ch_tmpl_fft) {
         ChirpTables t = build_chirp_tables();
-        C_TRY(upload(&h->d_ch_tw, t.tw));
+        if (!h->d_ch_tw) C_TRY(upload(&h->d_ch_tw, t.tw));
         C_TRY(upload(&h->d_ch_tmpl, t.tmpl));
         h->ch_energy[0] = t.energy[0]; h->ch_energy[1] = t.energy[1];
         C_TRY(hipMalloc(&h->d_ch_tmpl_fft, static_cast<size_t>(2) * kChFft * sizeof(float2)));
@@ -1057,6 +1074,62 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
         }
         A.sub = 0; A.n_sub = nb;
         hipLaunchKernelGGL(chirp_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return RIA_OK;
+}
+
+// SimulatedChannel::applyTxCFO for a batch of transmissions (cfo_kernels.hip.h)
+int ria_gpu_tx_cfo_batch(ria_gpu_handle h, const float* samples_dev, int64_t stride, int n_samples, int n_buffers,
+                         const float* cfo_hz_dev, float* phase_inout_dev, float* out_dev, int64_t out_stride, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_buffers == 0 || n_samples == 0) return RIA_OK;
+    if (!samples_dev || !out_dev || !cfo_hz_dev || n_buffers < 0 || n_samples < 0 || stride < n_samples || out_stride < n_samples || samples_dev == out_dev)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_tx_cfo_batch: bad arguments");
+    if (n_samples > (1 << kTxCfoMaxLog)) return fail(h, RIA_ERR_UNSUPPORTED, "ria_gpu_tx_cfo_batch: at most 131072 samples per transmission");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->d_ch_tw) { ChirpTables t = build_chirp_tables(); HIP_TRY(h, upload(&h->d_ch_tw, t.tw)); }
+    int L = 0;
+    while ((1 << L) < n_samples) ++L;
+    const size_t N = size_t(1) << L, per = 2 * N * sizeof(float2) + static_cast<size_t>(n_samples) * sizeof(float);
+    // buffers per pass: the workspace of one pass stays under 256 MiB (and the grid's y extent under 65536)
+    const int chunk = static_cast<int>(std::min<size_t>(std::min(n_buffers, 32768), std::max<size_t>(1, (size_t(256) << 20) / per)));
+    const size_t need = per * static_cast<size_t>(chunk);
+    if (need > h->txcfo_ws_bytes) {
+        if (h->d_txcfo_ws) { HIP_TRY(h, hipStreamSynchronize(s)); (void)hipFree(h->d_txcfo_ws); }
+        h->d_txcfo_ws = nullptr; h->txcfo_ws_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_txcfo_ws, need));
+        h->txcfo_ws_bytes = need;
+    }
+    for (int first = 0; first < n_buffers; first += chunk) {
+        const int nb = std::min(chunk, n_buffers - first);
+        TxCfoArgs A{};
+        A.in = samples_dev + static_cast<int64_t>(first) * stride; A.in_stride = stride;
+        A.out = out_dev + static_cast<int64_t>(first) * out_stride; A.out_stride = out_stride;
+        A.n = n_samples; A.log2n = L; A.n_buffers = nb; A.cfo_hz = cfo_hz_dev + first; A.phase = phase_inout_dev ? phase_inout_dev + first : nullptr;
+        A.tw = static_cast<const float2*>(h->d_ch_tw);
+        A.w1 = static_cast<float2*>(h->d_txcfo_ws); A.w2 = A.w1 + static_cast<size_t>(nb) * N; A.ph = reinterpret_cast<float*>(A.w2 + static_cast<size_t>(nb) * N);
+        hipLaunchKernelGGL(txcfo_phase_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
+        for (int inv = 0; inv < 2; ++inv) {
+            float2* dst = inv ? A.w2 : A.w1;
+            for (int S0 = 0; S0 < L;) {
+                const int G = std::min(6, L - S0);
+                const int mode = (S0 == 0) ? (inv ? 2 : 1) : 0;
+                const dim3 grid(static_cast<unsigned>(((N >> G) + 255) / 256), nb), blk(256);
+                const float2* src = A.w1;
+                switch (G) {
+                    case 1: hipLaunchKernelGGL(txcfo_fft_pass<1>, grid, blk, 0, s, A, src, dst, S0, mode, inv); break;
+                    case 2: hipLaunchKernelGGL(txcfo_fft_pass<2>, grid, blk, 0, s, A, src, dst, S0, mode, inv); break;
+                    case 3: hipLaunchKernelGGL(txcfo_fft_pass<3>, grid, blk, 0, s, A, src, dst, S0, mode, inv); break;
+                    case 4: hipLaunchKernelGGL(txcfo_fft_pass<4>, grid, blk, 0, s, A, src, dst, S0, mode, inv); break;
+                    case 5: hipLaunchKernelGGL(txcfo_fft_pass<5>, grid, blk, 0, s, A, src, dst, S0, mode, inv); break;
+                    default: hipLaunchKernelGGL(txcfo_fft_pass<6>, grid, blk, 0, s, A, src, dst, S0, mode, inv); break;
+                }
+                S0 += G;
+            }
+        }
+        hipLaunchKernelGGL(txcfo_rotate_kernel, dim3((n_samples + 255) / 256, nb), dim3(256), 0, s, A);
     }
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;

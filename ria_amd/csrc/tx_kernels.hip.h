@@ -448,6 +448,11 @@ struct ChanExactArgs {
     float alpha, one_minus_alpha, ns, g1, g2, noise_gain;
     uint32_t seed; uint64_t first_frame;
     const uint32_t* seeds;   // nullable: per-frame mt19937 seeds (then seed / first_frame are not used)
+    // CFO impairment of the channel object (hf_channel.hpp:47-51 Config::cfo_hz / random_cfo_max_hz, :97-102, :172-241)
+    const float* cfo_hz;     // nullable: per-frame Config::cfo_hz (else cfo_all)
+    float cfo_all;
+    float random_cfo_max;    // > 0: the frame's CFO is the constructor's uniform draw from the frame's own generator
+    float* actual_cfo_out;   // nullable [n_frames]: getActualCFO()
 };
 __host__ __device__ inline int chan_exact_lds_bytes() { return 624 * 4 + kChanNbuf * 4 + 4 * kChanTile * 4 + kChanTile * 4 + 128 * 4 + 256 * 4 + 64; }
 
@@ -478,6 +483,18 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
     const float nstd = rms * A.noise_gain;
     mt_seed_wave(st, A.seeds ? A.seeds[blockIdx.x] : A.seed + static_cast<uint32_t>(A.first_frame + blockIdx.x), lane);
     for (int i = lane; i < 128; i += 64) hist[i] = 0.0f;
+    // The constructor's CFO draw (hf_channel.hpp:97-102) takes the generator's FIRST word, so the normal
+    // distribution's pairs start at word 1 and straddle the twists: (623 of one twist, 0 of the next).
+    const bool odd = A.random_cfo_max > 0.0f;
+    bool first_twist = true;
+    uint32_t carry = 0u;
+    float actual_cfo = A.cfo_hz ? A.cfo_hz[blockIdx.x] : A.cfo_all;
+    // applyCFO state (hf_channel.hpp:182-241): lanes 0/1 own the running sums of I/Q, lane 2 the CFO phase
+    float* ibt = xt;                           // tile of I_bb (xt is free once the delayed-tap history is saved)
+    float* qbt = fr + 3 * kChanTile;           // tile of Q_bb; fr[0..3*tile) = running sums I, Q and the phase per sample
+    float* ibh = tmp + 128;                    // last 48 I_bb / Q_bb of the previous tile
+    float* qbh = tmp + 176;
+    float run = 0.0f;
     int have = 0;
     const int per = A.fading ? 5 : 1;
     float fc = (lane == 0 || lane == 2) ? 1.0f : 0.0f;       // lanes 0..3: f1.re, f1.im, f2.re, f2.im
@@ -487,13 +504,17 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
         const int need = per * tn;
         while (have < need) {
             mt_twist_wave(st, lane);
+            if (odd && first_twist)   // uniform_real_distribution<float>(-max, max): canonical * (b - a) + a
+                actual_cfo = mt_canonical(st[0]) * (A.random_cfo_max - (-A.random_cfo_max)) + (-A.random_cfo_max);
             for (int pb = 0; pb < 312; pb += 64) {
                 const int p = pb + lane;
                 bool acc = false;
                 float u = 0.f, v = 0.f, r2 = 1.f;
-                if (p < 312) {
-                    u = 2.0f * mt_canonical(st[2 * p]) - 1.0f;
-                    v = 2.0f * mt_canonical(st[2 * p + 1]) - 1.0f;
+                if (p < 312 && !(odd && first_twist && p == 0)) {
+                    const uint32_t wu = !odd ? st[2 * p] : (p == 0) ? carry : st[2 * p - 1];
+                    const uint32_t wv = !odd ? st[2 * p + 1] : st[2 * p];
+                    u = 2.0f * mt_canonical(wu) - 1.0f;
+                    v = 2.0f * mt_canonical(wv) - 1.0f;
                     r2 = u * u + v * v;
                     acc = !(r2 > 1.0f || r2 == 0.0f);
                 }
@@ -506,6 +527,8 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
                 }
                 have += 2 * __popcll(mask);
             }
+            if (odd) carry = st[623];
+            first_twist = false;
             wave_sync();
         }
         for (int i = lane; i < tn; i += 64) xt[i] = x[base + i];
@@ -549,11 +572,65 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
         }
         have = left;
         wave_sync();
+        // ---- applyCFO on this tile (process() :172-174: |actual CFO| > 0.001 Hz; applyCFO returns early below 256 samples)
+        if (fabs_(actual_cfo) > 0.001f && n >= 256) {
+            const float inc = static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(actual_cfo) / static_cast<double>(48000u));
+            float cm[kChanTile / 64], sm[kChanTile / 64];
+#pragma unroll
+            for (int q = 0; q < kChanTile / 64; ++q) {           // mix to baseband at fc = 1500 Hz (:195-200)
+                const int i = 64 * q + lane;
+                cm[q] = 0.0f; sm[q] = 0.0f;
+                if (i < tn) {
+                    const float t = fdiv(static_cast<float>(base + i), 48000.0f);
+                    const float mp = static_cast<float>(static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(1500.0f) * static_cast<double>(t));
+                    cm[q] = cosf_glibc(mp); sm[q] = sinf_glibc(mp);
+                    const float o = x[base + i];                 // this lane's own store of the stage above
+                    ibt[i] = o * cm[q]; qbt[i] = o * sm[q];
+                }
+            }
+            wave_sync();
+            if (lane < 2) {                                      // 48-tap moving average as running sums (:204-217): serial by definition
+                const float* cur = lane ? qbt : ibt;
+                const float* old = lane ? qbh : ibh;
+                float* dst = fr + lane * kChanTile;
+                for (int i = 0; i < tn; ++i) {
+                    run += cur[i];
+                    if (base + i >= 48) run -= (i >= 48) ? cur[i - 48] : old[i];
+                    dst[i] = run;
+                }
+            } else if (lane == 2) {                              // CFO phase walk (:223-238): wraps only downwards
+                float* dst = fr + 2 * kChanTile;
+                for (int i = 0; i < tn; ++i) {
+                    dst[i] = run;
+                    run += inc;
+                    if (static_cast<double>(run) > static_cast<double>(2.0f) * 3.14159265358979323846)
+                        run = static_cast<float>(static_cast<double>(run) - static_cast<double>(2.0f) * 3.14159265358979323846);
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < kChanTile / 64; ++q) {
+                const int i = 64 * q + lane;
+                if (i < tn) {
+                    const int m = (base + i + 1 < 48) ? base + i + 1 : 48;
+                    const float If = fdiv(fr[i], static_cast<float>(m)), Qf = fdiv(fr[kChanTile + i], static_cast<float>(m));
+                    const float ph = fr[2 * kChanTile + i];
+                    const float cc = cosf_glibc(ph), cs = sinf_glibc(ph);
+                    const float Ic = If * cc - Qf * cs, Qc = If * cs + Qf * cc;
+                    x[base + i] = 2.0f * (Ic * cm[q] - Qc * sm[q]);
+                }
+            }
+            wave_sync();
+            if (lane < 48 && tn == kChanTile) { const float a = ibt[kChanTile - 48 + lane], b = qbt[kChanTile - 48 + lane]; ibh[lane] = a; qbh[lane] = b; }
+            wave_sync();
+        }
     }
+    if (A.actual_cfo_out && lane == 0) A.actual_cfo_out[blockIdx.x] = actual_cfo;
 }
 
 inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t first_frame, float* samples, long long stride,
-                                 int frame_samples, int n_frames, hipStream_t s, const uint32_t* seeds = nullptr) {
+                                 int frame_samples, int n_frames, hipStream_t s, const uint32_t* seeds = nullptr,
+                                 const float* cfo_hz = nullptr, float cfo_all = 0.0f, float random_cfo_max = 0.0f, float* actual_cfo_out = nullptr) {
     float delay_ms = 0, doppler = 0, g1 = 1.0f, g2 = 0.0f;  // presets hf_channel.hpp:411-488
     int fading = 1, multipath = 1;
     switch (kind) {
@@ -574,6 +651,7 @@ inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t
     A.g1 = g1; A.g2 = g2;
     A.noise_gain = powf(10.0f, -snr_db / 20.0f);
     A.seed = seed; A.first_frame = first_frame; A.seeds = seeds;
+    A.cfo_hz = cfo_hz; A.cfo_all = cfo_all; A.random_cfo_max = random_cfo_max; A.actual_cfo_out = actual_cfo_out;
     hipLaunchKernelGGL(channel_exact_kernel, dim3(n_frames), dim3(64), chan_exact_lds_bytes(), s, A);
 }
 

@@ -313,6 +313,35 @@ class RxEngine:
                                                                 _stream_ptr()))
         return samples
 
+    def channel_exact_cfo_(self, samples, kind, snr_db, seeds, cfo_hz=None, random_cfo_max_hz=0.0):
+        """Reference-identical channel incl. its CFO impairment (Config::cfo_hz per frame / random_cfo_max_hz + applyCFO);
+        in place.  Returns the per-frame getActualCFO() tensor."""
+        n, fs = samples.shape
+        assert samples.dtype == torch.float32 and samples.is_contiguous()
+        if not torch.is_tensor(seeds):
+            seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32)).to(self.device)
+        assert seeds.numel() == n and seeds.element_size() == 4 and seeds.is_contiguous()
+        if cfo_hz is not None and not torch.is_tensor(cfo_hz):
+            cfo_hz = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(cfo_hz, np.float32), (n,)))).to(self.device)
+        assert cfo_hz is None or (cfo_hz.dtype == torch.float32 and cfo_hz.numel() == n and cfo_hz.is_contiguous())
+        actual = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._check(self.lib.ria_gpu_channel_exact_cfo_batch(self.h, int(kind), float(snr_db), _ptr(seeds), _ptr(cfo_hz), float(random_cfo_max_hz),
+                                                             _ptr(actual), _ptr(samples), fs, fs, n, _stream_ptr()))
+        return actual
+
+    def tx_cfo(self, samples, cfo_hz, phase=None):
+        """SimulatedChannel::applyTxCFO over a batch: samples float32 [n, len] on the device, cfo_hz scalar or [n];
+        phase float32 [n] accumulator (updated in place) or None.  Returns the shifted samples."""
+        n, L = samples.shape
+        assert samples.dtype == torch.float32 and samples.is_contiguous()
+        if not torch.is_tensor(cfo_hz):
+            cfo_hz = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(cfo_hz, np.float32), (n,)))).to(self.device)
+        assert cfo_hz.dtype == torch.float32 and cfo_hz.numel() == n and cfo_hz.is_contiguous()
+        assert phase is None or (phase.dtype == torch.float32 and phase.numel() == n and phase.is_contiguous())
+        out = torch.empty_like(samples)
+        self._check(self.lib.ria_gpu_tx_cfo_batch(self.h, _ptr(samples), L, L, n, _ptr(cfo_hz), _ptr(phase), _ptr(out), L, _stream_ptr()))
+        return out
+
     def burst_deinterleave(self, llr, burst_frames):
         """BurstInterleaver::deinterleave: llr float32 [n_groups*N, >=2592] physical -> logical (same shape)."""
         n, stride = llr.shape

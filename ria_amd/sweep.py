@@ -243,78 +243,93 @@ def run_ladder_chunk(engines, point, base_seed, point_index, start, n, max_tx=4,
 
 # ------------------------------------------------------------------------------------------------------------
 # Acquisition grid (BASELINE.json config 4): ZC + dual-chirp preambles in noise over a CFO x SNR grid.
-def analytic(x):
-    X = torch.fft.fft(x.double(), dim=-1)
-    n = x.shape[-1]
-    h = torch.zeros(n, dtype=torch.float64, device=x.device)
-    h[0] = 1
-    h[1:(n + 1) // 2] = 2
-    if n % 2 == 0:
-        h[n // 2] = 1
-    return torch.fft.ifft(X * h, dim=-1)
+#
+# Every buffer is built ON THE DEVICE by the library's reference-identical impairments, from a recipe that is a
+# function of global identifiers only (seed, grid point, kind, global preamble index), so that (a) a CPU checker can
+# rebuild the very same buffer from the recipe (oracle/pyoracle.py: acq_buffer) and compare every sample and every
+# detector field bit for bit, and (b) the counters do not depend on chunking or on the number of GPUs:
+#   preamble (ria_gpu_zc_preamble / ria_gpu_chirp_preamble, the reference generators' audio)
+#   -> cfo_model "tx":        SimulatedChannel::applyTxCFO of the transmission (tools/cli_simulator.cpp:298-341, the
+#                             analytic-signal rotation SURVEY.md 8d names for config 4; ria_gpu_tx_cfo_batch), placed at
+#                             `offset` in a silent buffer, then the AWGN WattersonChannel (noise sigma from the rms of
+#                             the non-zero samples; ria_gpu_channel_exact_seeded_batch with the recipe's mt19937 seed)
+#   -> cfo_model "watterson": the clean preamble placed in the buffer, then the AWGN WattersonChannel with
+#                             Config::cfo_hz = the grid CFO (its own applyCFO, hf_channel.hpp:182-241;
+#                             ria_gpu_channel_exact_cfo_batch).
+def acq_recipe(seed, grid_index, kind_index, indices, max_off):
+    """(offsets int64, mt19937 channel seeds uint32) of the preambles `indices` (global numbers) of one (grid point, kind)"""
+    idx = np.asarray(indices, dtype=np.uint64)
+    point = int(grid_index) * 8 + int(kind_index)
+    seeds = trial_seed32(seed, point, 0, idx)
+    offs = (trial_seed32(seed, point, 1, idx).astype(np.int64)) % np.int64(max_off + 1)
+    return offs, seeds
 
 
-def make_acq_buffers(pre, n, buf_len, max_off, snr_db, cfo_hz, gen, dev):
-    """pre: 1-D preamble tensor on dev.  Returns (buffers float32 [n, buf_len], offsets): the preamble at a random
-    offset in a noise-padded buffer, CFO by analytic-signal rotation, AWGN from the preamble's rms."""
-    L = pre.numel()
-    seg = pre
-    if cfo_hz != 0.0:
-        t = torch.arange(L, device=dev, dtype=torch.float64) / 48000.0
-        seg = (analytic(pre) * torch.exp(2j * np.pi * cfo_hz * t)).real.float()
-    rms = pre[pre != 0].pow(2).mean().sqrt()
-    sigma = rms * 10.0 ** (-snr_db / 20.0)
-    buf = torch.randn((n, buf_len), generator=gen, device=dev) * sigma
-    offs = torch.randint(0, max_off + 1, (n,), generator=gen, device=dev)
-    idx = offs[:, None] + torch.arange(L, device=dev)[None, :]
-    buf.scatter_add_(1, idx, seg[None, :].expand(n, -1).contiguous())
-    return buf.contiguous(), offs
+def make_acq_buffers(engine, pre, buf_len, offs, seeds, snr_db, cfo_hz, cfo_model="tx"):
+    """pre: 1-D preamble tensor on the engine's device; offs / seeds: the recipe of each buffer (acq_recipe).
+    Returns float32 [n, buf_len] on the device."""
+    dev = pre.device
+    n, L = len(offs), pre.numel()
+    seg = pre[None, :].contiguous()
+    if cfo_model == "tx":
+        seg = engine.tx_cfo(seg, float(cfo_hz))
+    buf = torch.zeros((n, buf_len), dtype=torch.float32, device=dev)
+    offs_t = torch.from_numpy(np.ascontiguousarray(offs, np.int64)).to(dev)
+    buf.scatter_(1, offs_t[:, None] + torch.arange(L, device=dev)[None, :], seg.expand(n, -1).contiguous())   # placement only
+    if cfo_model == "tx":
+        engine.channel_exact_seeded_(buf, 0, snr_db, seeds)
+    else:
+        engine.channel_exact_cfo_(buf, 0, snr_db, seeds, cfo_hz=float(cfo_hz))
+    return buf
 
 
 ACQ_GRID = [(c, s) for c in (-50.0, -25.0, 0.0, 25.0, 50.0) for s in (-10.0, -5.0, 0.0, 5.0, 10.0)]
 ACQ_COUNTERS = ("n", "zc_detected", "zc_timing_ok", "chirp_success", "chirp_timing_ok", "chirp_cfo_ok")
+ZC_ROOT_MASK_ALL, ZC_THRESHOLD, CHIRP_THRESHOLD = 15, 0.3, 0.15
 
 
-def run_acquisition_grid(engine, dev, cdev, preambles, seed, kinds=None, grid=None, sync=None):
-    """Preambles are dealt to the ranks in fixed-size chunks (chunk c of a (grid point, kind) goes to rank c % world) and
-    every chunk draws its buffers from its own generator seeded by (seed, grid point, kind, chunk index): the counters do
-    not depend on the number of ranks.  The only collectives are the all-reduce of the counters and of the wall times
-    (cdev: where those few bytes live - the GPU for RCCL, the CPU for gloo).
+def acq_tally(kind, res, offs, pre_len, cfo_hz):
+    """Counter contributions of one chunk from the detector's result records: (n, detected / success, timing ok[, cfo ok])"""
+    offs = np.asarray(offs, np.int64)
+    if kind == "zc":
+        det = res["detected"].astype(bool)
+        ok = np.abs(res["start_sample"].astype(np.int64) - (offs + pre_len)) <= 4
+        return np.array([len(offs), det.sum(), (det & ok).sum(), 0, 0, 0], np.int64)
+    suc = res["success"].astype(bool)
+    ok = np.abs(res["up_chirp_start"].astype(np.int64) - offs) <= 2
+    cok = np.abs(res["cfo_hz"] - np.float32(cfo_hz)) <= 1.0
+    return np.array([0, 0, 0, suc.sum(), (suc & ok).sum(), (suc & cok).sum()], np.int64)
+
+
+def run_acquisition_grid(engine, dev, cdev, preambles, seed, kinds=None, grid=None, sync=None, cfo_model="tx"):
+    """Preambles are dealt to the ranks in fixed-size chunks (chunk c of a (grid point, kind) goes to rank c % world); the
+    recipe of a buffer depends on its global index only, so the counters do not depend on the number of ranks.  The only
+    collectives are the all-reduce of the counters and of the wall times (cdev: where those few bytes live - the GPU for
+    RCCL, the CPU for gloo).
     kinds: [(name, preamble tensor, buffer length, largest offset, chunk)]; returns (counters [len(grid), 6], [t_zc, t_chirp])."""
     import time
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     grid = ACQ_GRID if grid is None else grid
     sync = sync or (lambda: None)
-    cnt = torch.zeros((len(grid), 6), dtype=torch.int64, device=dev)
+    cnt = np.zeros((len(grid), 6), np.int64)
     t_zc = t_ch = 0.0
     for gi, (cfo, snr) in enumerate(grid):
         for ki, (kind, pre, buf_len, max_off, chunk) in enumerate(kinds):
             for start, n in shard_range(preambles, rank, world, chunk):
-                gen = torch.Generator(device=dev)
-                gen.manual_seed((int(seed) * 1000003 + gi * 8191 + ki * 131 + start // chunk) & 0x7FFFFFFFFFFFFFFF)
-                buf, offs = make_acq_buffers(pre, n, buf_len, max_off, snr, cfo, gen, dev)
+                offs, seeds = acq_recipe(seed, gi, ki, np.arange(start, start + n), max_off)
+                buf = make_acq_buffers(engine, pre, buf_len, offs, seeds, snr, cfo, cfo_model)
                 sync()
                 t0 = time.perf_counter()
                 if kind == "zc":
                     # ZC alone is unambiguous to +-23.6 Hz (zc_sync.hpp:55-58): the chirp's CFO is handed to it as known_cfo
-                    r = engine.sync_zc(buf, 0.3, 15, torch.full((n,), cfo, dtype=torch.float32, device=dev))
+                    r = engine.sync_zc(buf, ZC_THRESHOLD, ZC_ROOT_MASK_ALL, torch.full((n,), cfo, dtype=torch.float32, device=dev))
                     t_zc += time.perf_counter() - t0
-                    det = torch.from_numpy(r["detected"].astype(np.int64)).to(dev)
-                    ok = (torch.from_numpy(r["start_sample"].astype(np.int64)).to(dev) - (offs + pre.numel())).abs() <= 4
-                    cnt[gi, 0] += n
-                    cnt[gi, 1] += det.sum()
-                    cnt[gi, 2] += (det.bool() & ok).sum()
                 else:
-                    r = engine.sync_chirp(buf, 0.15)
+                    r = engine.sync_chirp(buf, CHIRP_THRESHOLD)
                     t_ch += time.perf_counter() - t0
-                    suc = torch.from_numpy(r["success"].astype(np.int64)).to(dev)
-                    ok = (torch.from_numpy(r["up_chirp_start"].astype(np.int64)).to(dev) - offs).abs() <= 2
-                    cok = torch.from_numpy(np.abs(r["cfo_hz"] - cfo) <= 1.0).to(dev)
-                    cnt[gi, 3] += suc.sum()
-                    cnt[gi, 4] += (suc.bool() & ok).sum()
-                    cnt[gi, 5] += (suc.bool() & cok).sum()
-    cnt = cnt.to(cdev)
+                cnt[gi] += acq_tally(kind, r, offs, pre.numel(), cfo)
+    cnt = torch.from_numpy(cnt).to(cdev)
     tt = torch.tensor([t_zc, t_ch], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)

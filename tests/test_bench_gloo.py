@@ -123,9 +123,19 @@ def test_bench_control_flow_world_size_2():
 
 
 class StubSync:
-    """sync_zc / sync_chirp stand-ins: 'detect' from the buffer content only (energy of fixed windows)"""
+    """CPU stand-ins for the engine calls of the acquisition grid: the impairments keep the library's contract (a
+    function of the recipe only: per-buffer seed, CFO), the detectors 'detect' from the buffer content only"""
     ZC = np.dtype([("detected", "<i4"), ("start_sample", "<i4")])
     CH = np.dtype([("success", "<i4"), ("up_chirp_start", "<i4"), ("cfo_hz", "<f4")])
+
+    def tx_cfo(self, seg, cfo_hz):
+        return seg * float(1.0 + cfo_hz / 1000.0)
+
+    def channel_exact_seeded_(self, buf, kind, snr_db, seeds):
+        s = torch.from_numpy((np.asarray(seeds, np.uint32) % 1000).astype(np.float32) / 1000.0)
+        ramp = torch.arange(buf.shape[1], dtype=torch.float32)[None, :] % 7
+        buf += (s[:, None] - 0.5) * 10.0 ** (-snr_db / 20.0) * (ramp - 3.0) * 0.05
+        return buf
 
     def sync_zc(self, buf, thr, mask, cfo):
         r = np.zeros(buf.shape[0], self.ZC)

@@ -1,0 +1,193 @@
+"""GPU parity tests of BASELINE.json config 4 (run with -m gpu on an MI355X): ZC + dual-chirp acquisition over the
++-50 Hz CFO x 5-SNR grid, with the REFERENCE's own CFO impairments on the device:
+  * SimulatedChannel::applyTxCFO (tools/cli_simulator.cpp:298-341)      -> ria_gpu_tx_cfo_batch
+  * WattersonChannel Config::cfo_hz / random_cfo_max_hz + applyCFO (hf_channel.hpp:97-102,172-241)
+                                                                          -> ria_gpu_channel_exact_cfo_batch
+Everything is bit-exact: the synthesised buffers sample for sample, the detectors' records field for field, against the
+CPU oracle, the compiled reference library where it travelled (oracle/_ref) and the vectors recorded from the reference."""
+import concurrent.futures as cf
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from test_gpu_parity import _chirp_fields, _zc_fields, bits, dev, engine
+from test_oracle_golden import _txcfo_input, acq_grid_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def checker(oracle):
+    """the compiled reference where the build shipped it (its .so travels with the snapshot), else the pinned restatement"""
+    return po.Ref() if po.Ref.available() else oracle
+
+
+def test_tx_cfo_bit_exact_vs_reference_golden_and_oracle(oracle, golden):
+    import torch
+    e = engine("QAM16", "R1_2")
+    g = golden("cfo_impairment")
+    for i, (n, cfo, ph) in enumerate(g["txcfo_cases"]):
+        x = _txcfo_input(oracle, int(n), i)
+        phase = dev(np.array([ph], np.float32))
+        y = e.tx_cfo(dev(x[None, :]), float(cfo), phase).cpu().numpy()[0]
+        assert np.array_equal(bits(y), bits(g[f"txcfo_y_{i}"])), (i, n, cfo, np.nonzero(bits(y) != bits(g[f"txcfo_y_{i}"]))[0][:4])
+        assert phase.cpu().numpy()[0] == g[f"txcfo_phase_{i}"], i
+    # a ragged batch: every power-of-two boundary the pass planner meets, per-buffer offsets and accumulators, the frame
+    # and preamble lengths of the other configurations, the largest transform (131072)
+    rng = np.random.default_rng(404)
+    for n in (3, 64, 65, 127, 128, 1000, 2512, 8192, 8193, 18432, 57600, 131072):
+        nb = 3 if n > 60000 else 7
+        X = (rng.standard_normal((nb, n)) * 0.3).astype(np.float32)
+        cfo = np.array([50.0, -50.0, 25.0, 0.0005, -13.25, 3.0, -25.0][:nb], np.float32)
+        ph0 = np.array([0.0, 3.1, -3.1, 0.7, 1.0, -2.0, 0.1][:nb], np.float32)
+        phase = dev(ph0.copy())
+        Y = e.tx_cfo(dev(X), dev(cfo), phase).cpu().numpy()
+        P = phase.cpu().numpy()
+        for b in range(nb):
+            exp, p1 = oracle.apply_tx_cfo(X[b], float(cfo[b]), float(ph0[b]))
+            assert np.array_equal(bits(Y[b]), bits(exp)), (n, b, np.nonzero(bits(Y[b]) != bits(exp))[0][:4])
+            assert P[b] == np.float32(p1), (n, b, P[b], p1)
+    assert e.tx_cfo(torch.zeros((0, 100), dtype=torch.float32, device="cuda"), torch.zeros(0, dtype=torch.float32, device="cuda")).shape == (0, 100)
+
+
+def test_channel_cfo_bit_exact_vs_reference_golden_and_oracle(oracle, golden):
+    e = engine("QAM16", "R1_2")
+    g = golden("cfo_impairment")
+    x = golden("channel_vectors")["x"]
+    for i, (kind, cfo, rmax) in enumerate(g["chancfo_cases"]):
+        buf = dev(x[None, :].copy())
+        actual = e.channel_exact_cfo_(buf, int(kind), 15.0, np.array([177 + i], np.uint32), cfo_hz=float(cfo), random_cfo_max_hz=float(rmax))
+        y = buf.cpu().numpy()[0]
+        assert np.array_equal(bits(y), bits(g[f"chancfo_y_{i}"])), (i, kind, cfo, rmax, np.nonzero(bits(y) != bits(g[f"chancfo_y_{i}"]))[0][:4])
+        assert actual.cpu().numpy()[0] == g[f"chancfo_actual_{i}"]
+    buf = dev(x[None, :255].copy())
+    e.channel_exact_cfo_(buf, 0, 10.0, np.array([5], np.uint32), cfo_hz=25.0)
+    assert np.array_equal(bits(buf.cpu().numpy()[0]), bits(g["chancfo_short"]))
+    # frames of the named shape and an acquisition-sized buffer, all five presets, fixed and drawn offsets, per-frame CFOs
+    rng = np.random.default_rng(11)
+    frames = []
+    for f in range(6):
+        s, _, _ = oracle.tx_frame(po.QAM16, po.R1_2, rng.integers(0, 256, 141, dtype=np.uint8), f)
+        frames.append(s * np.float32(0.8 / np.abs(s).max()))
+    X = np.stack(frames)
+    X[2, :900] = 0.0
+    seeds = np.arange(6, dtype=np.uint32) * 7919 + 3
+    cfos = np.array([50.0, -50.0, 12.5, 0.0, -0.0005, 30.0], np.float32)
+    for kind in range(5):
+        for rmax in (0.0, 40.0):
+            buf = dev(X.copy())
+            actual = e.channel_exact_cfo_(buf, kind, 18.0, seeds, cfo_hz=dev(cfos), random_cfo_max_hz=rmax).cpu().numpy()
+            Y = buf.cpu().numpy()
+            for f in range(6):
+                exp, a = oracle.channel_cfo(kind, 18.0, int(seeds[f]), X[f], float(cfos[f]), rmax)
+                assert np.array_equal(bits(Y[f]), bits(exp)), (kind, rmax, f, np.nonzero(bits(Y[f]) != bits(exp))[0][:4])
+                assert actual[f] == np.float32(a)
+    pre = oracle.chirp_generate()
+    long = np.zeros((2, 120000), np.float32)
+    long[0, 30000:30000 + len(pre)] = pre
+    long[1, 100:100 + len(pre)] = pre
+    buf = dev(long.copy())
+    e.channel_exact_cfo_(buf, 0, 0.0, np.array([5, 6], np.uint32), cfo_hz=dev(np.array([-50.0, 50.0], np.float32)))
+    Y = buf.cpu().numpy()
+    for b in range(2):
+        exp, _ = oracle.channel_cfo(0, 0.0, 5 + b, long[b], (-50.0, 50.0)[b], 0.0)
+        assert np.array_equal(bits(Y[b]), bits(exp)), b
+
+
+def _grid_reference(chk, pres, kinds, seed, per_point, cfo_model, pool):
+    """per (kind, grid point): the recipe, the CPU-built buffers and the checker's result records"""
+    from ria_amd.sweep import ACQ_GRID, acq_recipe
+    jobs = []
+    for gi, (cfo, snr) in enumerate(ACQ_GRID):
+        for ki, (kind, buf_len, max_off) in enumerate(kinds):
+            offs, seeds = acq_recipe(seed, gi, ki, np.arange(per_point), max_off)
+            for q in range(per_point):
+                jobs.append((kind, gi, cfo, snr, buf_len, int(offs[q]), int(seeds[q])))
+
+    def run(j):
+        kind, gi, cfo, snr, buf_len, off, sd = j
+        buf = po.acq_buffer(chk, pres[kind], buf_len, off, sd, snr, cfo, cfo_model)
+        return buf, (chk.zc_detect(buf, 0.3, 15, cfo) if kind == "zc" else chk.chirp_detect(buf, 0.15))
+    for kind in ("zc", "chirp"):                      # lazily built tables of the checkers: first call of each kind alone
+        run(next(j for j in jobs if j[0] == kind))
+    return jobs, list(pool.map(run, jobs))
+
+
+@pytest.mark.parametrize("cfo_model,per_point", [("tx", 32), ("watterson", 8)])
+def test_config4_whole_grid_bit_exact(oracle, golden, cfo_model, per_point):
+    """The 25-point grid x {ZC with known_cfo = the grid CFO (+-25 / +-50 Hz included), dual chirp} x per_point buffers:
+    the device-built buffers equal the CPU-built ones sample for sample and every field of every result record equals
+    the reference's (library or pinned oracle), for both CFO impairments of the reference."""
+    from ria_amd import sweep
+    e = engine("QAM16", "R1_2")
+    chk = checker(oracle)
+    pres = {"zc": e.zc_preamble(5), "chirp": e.chirp_preamble()}
+    assert np.array_equal(bits(pres["zc"]), bits(oracle.zc_generate(5))) and np.array_equal(bits(pres["chirp"]), bits(oracle.chirp_generate()))
+    kinds = (("zc", 4512, 2000), ("chirp", 120000, 62400))
+    seed = 424242 if cfo_model == "tx" else 434343
+    with cf.ThreadPoolExecutor(16) as pool:            # the checkers are C calls that release the GIL
+        jobs, ref = _grid_reference(chk, pres, kinds, seed, per_point, cfo_model, pool)
+    k = 0
+    n_det = {"zc": 0, "chirp": 0}
+    for gi, (cfo, snr) in enumerate(sweep.ACQ_GRID):
+        for ki, (kind, buf_len, max_off) in enumerate(kinds):
+            offs, seeds = sweep.acq_recipe(seed, gi, ki, np.arange(per_point), max_off)
+            buf = sweep.make_acq_buffers(e, dev(pres[kind]), buf_len, offs, seeds, snr, cfo, cfo_model)
+            if kind == "zc":
+                out = _zc_fields(e.sync_zc(buf, 0.3, 15, dev(np.full(per_point, cfo, np.float32))))
+            else:
+                out = _chirp_fields(e.sync_chirp(buf, 0.15))
+            B = buf.cpu().numpy()
+            for q in range(per_point):
+                assert jobs[k][:2] == (kind, gi)
+                exp_buf, exp = ref[k]
+                assert np.array_equal(bits(B[q]), bits(exp_buf)), (cfo_model, kind, cfo, snr, q, np.nonzero(bits(B[q]) != bits(exp_buf))[0][:4])
+                assert np.array_equal(bits(out[q]), bits(exp)), (cfo_model, kind, cfo, snr, q, out[q], exp)
+                n_det[kind] += int(exp[0])
+                k += 1
+    assert n_det["chirp"] >= 20 * per_point and n_det["zc"] >= 8 * per_point, n_det
+    if cfo_model == "tx":                                # the same recipe at the fixture's seed: records taken from the reference itself
+        import zlib
+        for kind, gi, cfo, snr, buf_len, off, sd, crc, rec in acq_grid_cases(golden):
+            buf = sweep.make_acq_buffers(e, dev(pres[kind]), buf_len, np.array([off]), np.array([sd], np.uint32), snr, cfo, "tx")
+            assert zlib.crc32(buf.cpu().numpy()[0].tobytes()) == crc, (kind, gi)
+            out = _zc_fields(e.sync_zc(buf, 0.3, 15, dev(np.array([cfo], np.float32)))) if kind == "zc" else _chirp_fields(e.sync_chirp(buf, 0.15))
+            assert np.array_equal(bits(out[0]), bits(rec)), (kind, gi, out[0], rec)
+
+
+def test_run_acquisition_grid_on_the_real_engine_equals_a_per_buffer_reference_tally(oracle):
+    """sweep.run_acquisition_grid (the driver tools/run_acquisition_grid.py shards over the GPUs) on the real engine, at a
+    small count with chunks that do not divide it: its counters equal a tally of the reference's per-buffer records."""
+    import torch
+    from ria_amd import sweep
+    e = engine("QAM16", "R1_2")
+    chk = checker(oracle)
+    d = torch.device("cuda")
+    pres = {"zc": e.zc_preamble(5), "chirp": e.chirp_preamble()}
+    grid = [(-50.0, -5.0), (-25.0, 0.0), (0.0, -10.0), (25.0, 5.0), (50.0, 10.0), (50.0, -10.0)]
+    n, seed = 21, 777
+    kinds = [("zc", dev(pres["zc"]), 4512, 2000, 8), ("chirp", dev(pres["chirp"]), 120000, 62400, 5)]
+    cnt, tt = sweep.run_acquisition_grid(e, d, d, n, seed, kinds, grid=grid, sync=torch.cuda.synchronize)
+    exp = np.zeros((len(grid), 6), np.int64)
+
+    def one(j):
+        gi, ki, q = j
+        kind, _, buf_len, max_off, _ = kinds[ki]
+        cfo, snr = grid[gi]
+        offs, seeds = sweep.acq_recipe(seed, gi, ki, np.array([q]), max_off)
+        buf = po.acq_buffer(chk, pres[kind], buf_len, int(offs[0]), int(seeds[0]), snr, cfo, "tx")
+        if kind == "zc":
+            r = chk.zc_detect(buf, sweep.ZC_THRESHOLD, sweep.ZC_ROOT_MASK_ALL, cfo)
+            rec = np.zeros(1, np.dtype([("detected", "<i4"), ("start_sample", "<i4")]))
+            rec["detected"], rec["start_sample"] = int(r[0]), int(r[2])
+        else:
+            r = chk.chirp_detect(buf, sweep.CHIRP_THRESHOLD)
+            rec = np.zeros(1, np.dtype([("success", "<i4"), ("up_chirp_start", "<i4"), ("cfo_hz", "<f4")]))
+            rec["success"], rec["up_chirp_start"], rec["cfo_hz"] = int(r[0]), int(r[1]), r[3]
+        return gi, sweep.acq_tally(kind, rec, offs, len(pres[kind]), cfo)
+    one((0, 0, 0)), one((0, 1, 0))                      # lazily built tables of the checkers
+    with cf.ThreadPoolExecutor(16) as pool:
+        for gi, row in pool.map(one, [(gi, ki, q) for gi in range(len(grid)) for ki in range(2) for q in range(n)]):
+            exp[gi] += row
+    assert np.array_equal(cnt, exp), (cnt, exp)
+    assert cnt[:, 0].tolist() == [n] * len(grid) and cnt[:, 3].sum() >= 4 * n and tt[0] > 0 and tt[1] > 0
