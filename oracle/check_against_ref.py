@@ -214,6 +214,34 @@ def main():
         n_det += int(b[0])
     check(f"cox_search ({n_det}/{len(cox_cases())} found by ref)", ok, worst)
 
+    # config 4 impairments: SimulatedChannel::applyTxCFO (tools/cli_simulator.cpp:298-341, compiled into the reference
+    # library from the tool's own translation unit) and WattersonChannel's cfo_hz / random_cfo_max_hz + applyCFO
+    ok, worst = True, ""
+    zc5 = R.zc_generate(5)
+    for name, x in (("zc", zc5), ("chirp", chirp), ("n=1", zc5[100:101]), ("n=2", zc5[100:102]), ("n=63", zc5[:63]),
+                    ("noise300", rng.standard_normal(300).astype(np.float32)), ("noise5000", rng.standard_normal(5000).astype(np.float32))):
+        for cfo in (-50.0, -25.0, 0.0, 25.0, 50.0, 13.7, 0.0005):
+            for ph in (0.0, 1.25, -3.0):
+                (a, pa), (b, pb) = O.apply_tx_cfo(x, cfo, ph), R.apply_tx_cfo(x, cfo, ph)
+                same = bits_equal(a, b) and bits_equal([pa], [pb])
+                ok &= same
+                if not same and not worst:
+                    worst = f"{name} cfo={cfo} phase={ph}"
+    check("applyTxCFO (7 inputs x 7 offsets x 3 accumulators)", ok, worst)
+    ok, worst = True, ""
+    s0, _, _ = O.tx_frame(po.QAM16, po.R1_2, rng.integers(0, 256, 141, dtype=np.uint8), 1)
+    frame = s0 * np.float32(0.8 / np.abs(s0).max())
+    acq = np.zeros(120000, np.float32); acq[30000:30000 + len(chirp)] = chirp
+    for name, x, snr in (("frame", frame, 15.0), ("chirp buffer", acq, 0.0), ("255 samples", frame[:255], 10.0)):
+        for kind in range(5):
+            for cfo, rmax in ((0.0, 0.0), (25.0, 0.0), (-50.0, 0.0), (10.5, 0.0), (0.0, 30.0), (5.0, 50.0), (0.0005, 0.0)):
+                (a, ca), (b, cb) = O.channel_cfo(kind, snr, 77 + kind, x, cfo, rmax), R.channel_cfo(kind, snr, 77 + kind, x, cfo, rmax)
+                same = bits_equal(a, b) and bits_equal([ca], [cb])
+                ok &= same
+                if not same and not worst:
+                    worst = f"{name} kind={kind} cfo={cfo} random_max={rmax}"
+    check("WattersonChannel cfo_hz / random_cfo_max_hz + applyCFO (3 inputs x 5 presets x 7 settings)", ok, worst)
+
     print("\n%s: %d failing group(s)" % ("PINNED" if fails == 0 else "MISMATCH", fails))
     return 1 if fails else 0
 

@@ -322,7 +322,7 @@ class RxEngine:
             seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32)).to(self.device)
         assert seeds.numel() == n and seeds.element_size() == 4 and seeds.is_contiguous()
         if cfo_hz is not None and not torch.is_tensor(cfo_hz):
-            cfo_hz = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(cfo_hz, np.float32), (n,)))).to(self.device)
+            cfo_hz = torch.from_numpy(np.full(n, cfo_hz, np.float32) if np.ndim(cfo_hz) == 0 else np.ascontiguousarray(cfo_hz, np.float32)).to(self.device)
         assert cfo_hz is None or (cfo_hz.dtype == torch.float32 and cfo_hz.numel() == n and cfo_hz.is_contiguous())
         actual = torch.zeros(n, dtype=torch.float32, device=self.device)
         self._check(self.lib.ria_gpu_channel_exact_cfo_batch(self.h, int(kind), float(snr_db), _ptr(seeds), _ptr(cfo_hz), float(random_cfo_max_hz),
@@ -335,7 +335,7 @@ class RxEngine:
         n, L = samples.shape
         assert samples.dtype == torch.float32 and samples.is_contiguous()
         if not torch.is_tensor(cfo_hz):
-            cfo_hz = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(cfo_hz, np.float32), (n,)))).to(self.device)
+            cfo_hz = torch.from_numpy(np.full(n, cfo_hz, np.float32) if np.ndim(cfo_hz) == 0 else np.ascontiguousarray(cfo_hz, np.float32)).to(self.device)
         assert cfo_hz.dtype == torch.float32 and cfo_hz.numel() == n and cfo_hz.is_contiguous()
         assert phase is None or (phase.dtype == torch.float32 and phase.numel() == n and phase.is_contiguous())
         out = torch.empty_like(samples)

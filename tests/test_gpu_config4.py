@@ -145,7 +145,10 @@ def test_config4_whole_grid_bit_exact(oracle, golden, cfo_model, per_point):
                 assert np.array_equal(bits(out[q]), bits(exp)), (cfo_model, kind, cfo, snr, q, out[q], exp)
                 n_det[kind] += int(exp[0])
                 k += 1
-    assert n_det["chirp"] >= 20 * per_point and n_det["zc"] >= 8 * per_point, n_det
+    if cfo_model == "tx":
+        assert n_det["chirp"] >= 20 * per_point and n_det["zc"] >= 8 * per_point, n_det
+    else:   # applyCFO's 48-sample average (a 500 Hz low-pass at baseband) removes most of a 300-2700 Hz chirp: the reference's
+        assert n_det["chirp"] >= per_point and n_det["zc"] >= per_point, n_det   # own comment calls this path distorting (cli_simulator.cpp:295-297)
     if cfo_model == "tx":                                # the same recipe at the fixture's seed: records taken from the reference itself
         import zlib
         for kind, gi, cfo, snr, buf_len, off, sd, crc, rec in acq_grid_cases(golden):
