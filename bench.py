@@ -29,7 +29,11 @@ ALGO_BYTES_FRAME = 18432 * 4 + 160          # samples in + pay
 ALGO_BYTES_DEMOD = 18432 * 4 + 2632 * 4     # demod kernel alone: samples in + LLRs out
 ALGO_BYTES_DECODE = 2592 * 4 + 160          # decode kernel alone: LLRs in + payload out
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_INSTS = 256 * 4 * 2.4e9 / 4        # wave64 VALU instructions/s: 1024 SIMD16 units x 2.4 GHz, 4 cycles per wave-instruction
+CLOCK_HZ = 2.4e9                             # MI355X_MICROARCH.md: max clock
+VALU_PEAK_INSTS = 256 * 4 * CLOCK_HZ / 2     # wave64 VALU instructions/s: 1024 SIMD-32 units, 2 cycles per wave64 instruction (the guide's
+                                             # wave-scheduling section; equals its 157.3 TFLOP/s vector peak); ONE wave alone issues every 4
+LDS_PEAK_CYCLES = 256 * CLOCK_HZ             # LDS-array cycles/s: one array per CU (SQ_LDS_IDX_ACTIVE counts its busy cycles)
+RECOVERY_STAGE = ("recovery_list_kernel", "recovery_stage1_kernel", "recovery_fill_kernel", "recovery_stage2_kernel")
 DECODE_STAGE = ("fast_primary_kernel", "fast_mark_kernel", "fast_stage_kernel", "fast_phase0_kernel", "fast_chain_kernel",
                 "fast_cascade_kernel", "fast_finalize_kernel", "frame_validate_kernel", "dual_phase0_kernel", "dual_cascade_kernel")
 
@@ -68,8 +72,10 @@ def matching_profile(suffix, src_hash):
 
 def cpu_baseline(frames_host, seconds_budget=20.0):
     """Reference CPU path on the host cores, bounded sample of the same workload (rank 0, N=1 only).
-    Prefers the compiled unmodified reference (oracle/_ref, kind 'reference'); falls back to the C
-    restatement (kind 'port').  The oracle is used here only as the timed baseline."""
+    Prefers the compiled unmodified reference (oracle/_ref, kind 'reference'): one OFDMChirpWaveform per thread, configured
+    once and reset() before every frame as gui::StreamingDecoder does (streaming_decoder.cpp:723; SURVEY.md 8d "one instance
+    per std::thread"), then process -> getSoftBits -> v2::decodeFixedFrame, all inside one C call per frame.  Falls back to the
+    C restatement (kind 'port').  The oracle is used here only as the timed baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     cores = host_cores()   # all host cores this process may use (SURVEY.md 8d), count stated in the result
@@ -83,33 +89,39 @@ def cpu_baseline(frames_host, seconds_budget=20.0):
             ref = None
     orc = po.Oracle()
 
-    def run_one(x):
+    def run_one(handle, x):
         if ref is not None:
-            llr, _, _, _ = ref.rx_process(po.QAM16, po.R1_2, x)
-            ref.decode_fixed_frame(llr, po.R1_2, True, 188)
+            ref.rx_frame(handle, x)
         else:
             llr, _ = orc.rx_process(po.QAM16, po.R1_2, x)
             orc.decode_fixed_frame(llr, po.R1_2, True, 188, flags=7)
 
-    run_one(frames_host[0])  # static-table warm-up before threading (frame_interleaver.cpp:13-48)
+    warm = ref.rx_open(po.QAM16, po.R1_2) if ref is not None else None
+    run_one(warm, frames_host[0])  # static-table warm-up before threading (frame_interleaver.cpp:13-48)
+    if ref is not None:
+        ref.rx_close(warm)
     n = len(frames_host)
     nxt = [0]
     done = [0]
     lock = threading.Lock()
-    t_end = time.perf_counter() + seconds_budget
+    t_end = [0.0]
 
     def worker():
+        handle = ref.rx_open(po.QAM16, po.R1_2) if ref is not None else None   # this thread's own waveform object
         while True:
             with lock:
                 i = nxt[0]
-                if i >= n or time.perf_counter() > t_end:
-                    return
+                if i >= n or time.perf_counter() > t_end[0]:
+                    break
                 nxt[0] += 1
-            run_one(frames_host[i])
+            run_one(handle, frames_host[i])
             with lock:
                 done[0] += 1
+        if ref is not None:
+            ref.rx_close(handle)
 
     t0 = time.perf_counter()
+    t_end[0] = t0 + seconds_budget
     ths = [threading.Thread(target=worker) for _ in range(cores)]
     for t in ths:
         t.start()
@@ -117,8 +129,9 @@ def cpu_baseline(frames_host, seconds_budget=20.0):
         t.join()
     dt = time.perf_counter() - t0
     return {"value": round(done[0] / dt, 2), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": f"{done[0]} frames of the timed workload's last batch (QAM16 R1/2, Watterson moderate 20 dB), "
-                      f"{dt:.1f} s wall on {cores} threads, full decodeFixedFrame incl. retry cascade"}
+            "sample": f"{done[0]} frames from the head of the timed workload's last batch (QAM16 R1/2, Watterson moderate 20 dB), "
+                      f"{dt:.1f} s wall on {cores} threads, one kept OFDMChirpWaveform per thread (reset per frame), process + full "
+                      f"decodeFixedFrame incl. retry cascade and CRC recovery"}
 
 
 def main(argv=None, engine_factory=None):
@@ -129,7 +142,7 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=25000, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=100000, help="frames per step per GPU (BASELINE.json configs[2]: 100k frames)")
     ap.add_argument("--channel", type=int, default=2, help="0 awgn 1 good 2 moderate 3 poor 4 flutter")
     ap.add_argument("--snr", type=float, default=20.0)
     ap.add_argument("--seed", type=int, default=20261004)
@@ -191,7 +204,7 @@ def main(argv=None, engine_factory=None):
     B = args.batch
     e = engine_factory(B) if stub else RxEngine("QAM16", "R1_2", device=local, max_batch=B)
     n_sets = args.steps + args.warmup
-    # every step gets its own input batch up to 16 resident batches (29 GB at the default size); longer runs cycle
+    # every step gets its own input batch up to 16 resident batches (16 x 7.4 GB at the default size); longer runs cycle
     # through them - the work per step is the same, nothing is cached between steps
     n_pool = min(n_sets, 16)
     batches, infos = [], []
@@ -242,7 +255,6 @@ def main(argv=None, engine_factory=None):
         llr, _ = e.demod(x, want_status=False)
         torch.cuda.synchronize()
         reps = 3
-        flags_nohost = capi.DECODE_PHASE0 | capi.DECODE_PERTURB
         for rep in range(reps + 1):          # the first pass is a warm-up (allocator, clocks) and is not counted
             if rep <= 1:
                 t_demod = t_decode = 0.0
@@ -250,57 +262,79 @@ def main(argv=None, engine_factory=None):
             llr, _ = e.demod(x, want_status=False)
             ev[1].record()
             ev[2].record()
-            e.decode(llr, flags=flags_nohost)
+            e.decode(llr, flags=capi.DECODE_FULL)     # everything the fused call runs after the demodulator, CRC recovery included
             ev[3].record()
             torch.cuda.synchronize()
             t_demod += ev[0].elapsed_time(ev[1]) / reps
             t_decode += ev[2].elapsed_time(ev[3]) / reps
+        del llr
     roof = None
     if t_decode is not None:
-        if t_decode >= t_demod:
-            dom, dur_ms, algo = "decode stage (fast_primary/mark/stage/phase0/chain/cascade/finalize + frame_validate kernels)", t_decode, ALGO_BYTES_DECODE * B
-            stage = DECODE_STAGE
-        else:
-            dom, dur_ms, algo = "demod_frames_kernel", t_demod, ALGO_BYTES_DEMOD * B
-            stage = ("demod_frames_kernel",)
-        achieved = algo / (dur_ms * 1e-3) / 1e9
-        # HBM traffic and instruction counts cannot be measured from inside the process: they come from the rocprofv3
-        # --pmc passes of THIS command (tools/measure_round.sh) summarised under profiles/ - and only from a summary
+        step_s = elapsed / args.steps
+        dec = t_decode >= t_demod
+        dom = ("decode stage (fast_primary/mark/stage/phase0/chain/cascade/finalize + frame_validate + recovery_* kernels: one "
+               "ria_gpu_decode_batch call)") if dec else "demod_frames_kernel"
+        dur_ms, algo = (t_decode, ALGO_BYTES_DECODE * B) if dec else (t_demod, ALGO_BYTES_DEMOD * B)
+        stage = (DECODE_STAGE + RECOVERY_STAGE) if dec else ("demod_frames_kernel",)
+        hbm_achieved = algo / (dur_ms * 1e-3) / 1e9
+        # HBM traffic, LDS-array cycles and instruction counts cannot be measured from inside the process: they come from the
+        # rocprofv3 --pmc passes of THIS command (tools/measure_round.sh) summarised under profiles/ - and only from a summary
         # whose recorded kernel-source hash equals the sources this run was built from; otherwise null with the reason.
         from ria_amd.srchash import csrc_sha256
         src = csrc_sha256()
-        traffic = traffic_src = valu = valu_issue = None
+        traffic = traffic_all = traffic_src = lds = valu_issue = None
+        in_stage = lambda k, names: k != "_meta" and any(n in k for n in names)   # noqa: E731
         tr, tr_path = matching_profile("_hbm_traffic_pmc.json", src)
         if tr is not None and tr["_meta"].get("frames_per_launch") == B:
-            traffic = int(sum(v["hbm_bytes_per_launch"] for k, v in tr.items() if k != "_meta" and any(n in k for n in stage)))
-            traffic_src = tr_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one launch = one whole step; FETCH_SIZE x2 for gfx950)"
+            traffic = int(sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tr.items() if in_stage(k, stage)))
+            traffic_all = int(sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tr.items() if k != "_meta"))
+            traffic_src = tr_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, RIA_NO_SPLIT: one launch = one whole step; FETCH_SIZE x2 for gfx950)"
         else:
             traffic_src = tr_path if tr is None else f"{tr_path} was measured at {tr['_meta'].get('frames_per_launch')} frames per launch, this run at {B}"
         sq, sq_path = matching_profile("_sq_utilisation_pmc.json", src)
         if sq is not None and sq["_meta"].get("frames_per_step") == B:
             m = sq["_meta"]
-            c = next((v for k, v in sq.items() if "fast_cascade_kernel" in k), None)
-            if c:
-                valu = {"kernel": "fast_cascade_kernel", "valu_busy_frac": c["valu_busy_frac"], "lds_busy_frac": c["lds_busy_frac"],
-                        "lds_bank_conflict_share": c["lds_bank_conflict_share"], "source": sq_path}
-            dec_insts = sum(v["valu_insts"] * v["launches"] for k, v in sq.items() if k != "_meta" and any(n in k for n in DECODE_STAGE)) / m["steps_counted"]
-            all_insts = sum(v["valu_insts"] * v["launches"] for k, v in sq.items() if k != "_meta" and any(n in k for n in DECODE_STAGE + ("demod_frames_kernel", "recovery_"))) / m["steps_counted"]
+            per_step = lambda field, names: sum(v[field] * v["launches"] for k, v in sq.items() if in_stage(k, names)) / m["steps_counted"]   # noqa: E731
+            dec_insts = per_step("valu_insts", DECODE_STAGE + RECOVERY_STAGE)
+            all_insts = per_step("valu_insts", DECODE_STAGE + RECOVERY_STAGE + ("demod_frames_kernel",))
             valu_issue = {"peak_insts_per_s": VALU_PEAK_INSTS, "unit": "wave64 VALU instructions (SQ_INSTS_VALU)",
                           "decode_stage": {"insts_per_step": int(dec_insts), "ms": round(t_decode, 3),
                                            "frac": round(dec_insts / (t_decode * 1e-3) / VALU_PEAK_INSTS, 4)},
-                          "fused_step": {"insts_per_step": int(all_insts), "ms": round(elapsed / args.steps * 1e3, 3),
-                                         "frac": round(all_insts / (elapsed / args.steps) / VALU_PEAK_INSTS, 4)},
-                          "model": "one VALU instruction per SIMD per 4 cycles (what a single wave sees); with several waves a SIMD retires "
-                                   "two-operand instructions faster and three-operand / packed ones at about this rate "
-                                   "(tools/probes/valu_rate_probe.hip), so frac bounds the VALU occupancy from above",
+                          "fused_step": {"insts_per_step": int(all_insts), "ms": round(step_s * 1e3, 3),
+                                         "frac": round(all_insts / step_s / VALU_PEAK_INSTS, 4)},
+                          "model": "2 cycles per wave64 VALU instruction per SIMD-32 (MI355X_MICROARCH.md wave scheduling = the 157.3 TFLOP/s "
+                                   "vector peak); a single wave alone issues one per 4 cycles (frac_single_wave_model = 2 x frac)",
                           "source": sq_path + " (instruction counts; the times are this run's)"}
+            if "lds_idx_active" in next(v for k, v in sq.items() if k != "_meta"):
+                st_names = stage
+                idx = per_step("lds_idx_active", st_names)
+                conf = per_step("lds_bank_conflict", st_names)
+                c = next((v for k, v in sq.items() if "fast_cascade_kernel" in k), None)
+                lds = {"idx_active_cycles_per_step": int(idx), "bank_conflict_cycles_per_step": int(conf),
+                       "bank_conflict_share": round(conf / max(idx, 1.0), 4),
+                       "achieved_Gcycles_per_s": round(idx / (dur_ms * 1e-3) / 1e9, 2), "peak_Gcycles_per_s": LDS_PEAK_CYCLES / 1e9,
+                       "frac": round(idx / (dur_ms * 1e-3) / LDS_PEAK_CYCLES, 4),
+                       "cascade_kernel_alone": None if c is None else {"lds_busy_frac": c["lds_busy_frac"], "lds_bank_conflict_share": c["lds_bank_conflict_share"],
+                                                                      "valu_issue_frac_2cyc": c.get("valu_issue_frac_2cyc")},
+                       "source": sq_path + " (SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT summed over the stage's kernels; the time is this run's)"}
         else:
-            valu = {"source": sq_path if sq is None else f"{sq_path}: other batch size"}
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
-                "limiter": "FP32 VALU issue + LDS, not HBM (SURVEY.md 8d): see valu_issue", "valu": valu, "valu_issue": valu_issue,
-                "kernel_source_sha256": src}
+            valu_issue = {"source": sq_path if sq is None else f"{sq_path}: other batch size"}
+        hbm = {"kernel": dom, "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
+               "algorithmic_bytes_per_launch": algo, "traffic": traffic}
+        fused_gbs = ALGO_BYTES_FRAME * B / step_s / 1e9
+        hbm_fused = {"kernel": "whole fused step (ria_gpu_rx_batch: samples in, payload out)", "achieved": round(fused_gbs, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(fused_gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_step": ALGO_BYTES_FRAME * B, "traffic": traffic_all}
+        if dec and lds is not None:
+            # what binds the dominant stage is the LDS array (gathers / stores of the min-sum messages), not HBM or MFMA: the
+            # roofline object states THAT unit; the HBM figures the contract defines stay beside it (hbm, hbm_fused_step)
+            roof = {"bound": "lds", "kernel": dom, "achieved": lds["achieved_Gcycles_per_s"], "peak": lds["peak_Gcycles_per_s"],
+                    "unit": "G LDS-array cycles/s (256 CUs x 2.4 GHz)", "frac": lds["frac"], "traffic": traffic}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": traffic}
+        roof.update({"traffic_source": traffic_src, "hbm": hbm, "hbm_fused_step": hbm_fused, "lds": lds, "valu_issue": valu_issue,
+                     "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
+                     "limiter": "LDS array + FP32 VALU issue, not HBM (SURVEY.md 8d: the fused chain's compulsory traffic is 0.1 % of HBM peak at 1 M frames/s)",
+                     "kernel_source_sha256": src})
 
     if rank == 0:
         res = {
@@ -328,7 +362,7 @@ def main(argv=None, engine_factory=None):
         }
         if world == 1 and not args.no_cpu_baseline and not args.steps_only:
             # bounded sample of the same workload: the last batch, as many of its frames as the host cores finish in ~20 s
-            res["cpu_baseline"] = cpu_baseline(batches[-1].cpu().numpy(), seconds_budget=20.0)
+            res["cpu_baseline"] = cpu_baseline(batches[-1][:4096].cpu().numpy(), seconds_budget=20.0)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

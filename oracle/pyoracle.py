@@ -382,6 +382,13 @@ class Ref:
         n = self.lib.ref_rx_frame(h, fp(x), len(x), cfo_hz, up(data), up(ok), fp(llr) if want_llr else None, len(llr) if want_llr else 0)
         return (n, data, ok, llr) if want_llr else (n, data, ok)
 
+    def rx_process_kept(self, h, samples, cfo_hz=0.0):
+        """process() + getSoftBits() on the kept object -> soft bits"""
+        x = np.ascontiguousarray(samples, np.float32)
+        llr = np.zeros(8 * NCAR * 64, np.float32)
+        n = self.lib.ref_rx_frame(h, fp(x), len(x), cfo_hz, None, None, fp(llr), len(llr))
+        return llr[:max(n, 0)].copy()
+
     def cox_search(self, samples, threshold=0.8, noise_floor=0.0, mod=QAM16, rate=R1_2):
         x = np.ascontiguousarray(samples, np.float32)
         out = np.zeros(3, np.float32)

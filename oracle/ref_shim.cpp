@@ -207,7 +207,8 @@ void* ref_rx_open(int mod, int rate) {
     return h;
 }
 void ref_rx_close(void* hv) { delete static_cast<RefRx*>(hv); }
-// returns the number of codewords decoded (0..4), -1 if process() produced no soft bits; llr_out nullable
+// returns the number of codewords decoded (0..4), -1 if process() produced no soft bits; llr_out nullable;
+// data_out == NULL: demodulate only and return the number of soft bits
 int ref_rx_frame(void* hv, const float* samples, int n, float cfo_hz, uint8_t* data_out, uint8_t* ok_out, float* llr_out, int max_llr) {
     auto* h = static_cast<RefRx*>(hv);
     h->rx->reset();
@@ -215,6 +216,7 @@ int ref_rx_frame(void* hv, const float* samples, int n, float cfo_hz, uint8_t* d
     bool ok = h->rx->process(SampleSpan(samples, n));
     std::vector<float> soft = h->rx->getSoftBits();
     if (llr_out) std::memcpy(llr_out, soft.data(), std::min<size_t>(soft.size(), max_llr) * sizeof(float));
+    if (!data_out) return ok ? static_cast<int>(soft.size()) : -1;   // process() + getSoftBits() only
     if (!ok || soft.size() < 2592) return -1;
     auto st = protocol::v2::decodeFixedFrame(soft, h->rate, true, h->bps);
     size_t bpc = protocol::v2::getBytesPerCodeword(h->rate);

@@ -72,11 +72,12 @@ def main():
         import pyoracle as po
         if po.Ref.available():
             R = po.Ref()
-            R.rx_process(po.QAM16, po.R1_2, xs[0])
+            kept = R.rx_open(po.QAM16, po.R1_2)    # one configured waveform object, reset() per frame (streaming_decoder.cpp:723)
+            R.rx_process_kept(kept, xs[0])
             tp, td = [], []
             for f in range(min(a.ref_frames, a.frames)):
                 t0 = time.perf_counter()
-                l = R.rx_process(po.QAM16, po.R1_2, xs[f])[0]
+                l = R.rx_process_kept(kept, xs[f])
                 t1 = time.perf_counter()
                 R.decode_fixed_frame(l, po.R1_2, True, 188)
                 t2 = time.perf_counter()
