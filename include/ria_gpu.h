@@ -321,6 +321,14 @@ typedef struct ria_mcdpsk_status {
 int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const float* samples_dev, int64_t stride,
                                int frame_samples, int n_frames, const float* cfo_hz_dev, const float* phase0_dev,
                                float* llr_out_dev, int llr_stride, ria_mcdpsk_status* status_dev, void* stream);
+/* Host-buffer forms for the single-frame MC-DPSK plug-in adaptor (MCDPSKWaveform::process -> getSoftBits,
+ * src/waveform/mc_dpsk_waveform.cpp:294-338; robustDecodeSingleCW, streaming_decoder.cpp:1028-1058): ordinary host memory
+ * in and out, staged on the handle's own stream, return when done.  demod: one frame (training + reference + data,
+ * n_samples >= 10 * 512); llr_out_host gets the soft bits as demodulateSoft returns them (count in status_out->n_llr). */
+int ria_gpu_mcdpsk_demod_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const float* samples_host, int n_samples, float cfo_hz,
+                              float phase0, float* llr_out_host, int max_llr, ria_mcdpsk_status* status_out);
+int ria_gpu_ldpc_decode_robust_host(ria_gpu_handle h, const float* llr_host, int n_cw, uint8_t* out_host, uint8_t* ok_host,
+                                    uint16_t* iters_host /* nullable */, uint8_t* tries_host /* nullable */);
 /* MultiCarrierDPSKModulator: generateTrainingSequence + generateReferenceSymbol + modulate(data) into a HOST
  * buffer (multi_carrier_dpsk.hpp:141-281); returns the sample count or -needed.  Bit-identical audio. */
 int ria_gpu_mcdpsk_modulate_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data, int n_bytes,

@@ -388,6 +388,46 @@ def cfo_fixture(R):
     return rec
 
 
+# ---- the MC-DPSK plug-in object itself (src/waveform/mc_dpsk_waveform.cpp) in StreamingDecoder's call order
+# (carriers, modulation, spreading, data_sync (0 dual chirp, 1 ZC), snr dB, transmitter CFO Hz, known CFO Hz, lead silence, channel preset)
+MCWF_CASES = [(10, po.DBPSK, 1, 0, 6.0, 0.0, 0.0, 3000, 0), (10, po.DBPSK, 4, 0, -6.0, 12.0, 0.0, 700, 0), (10, po.DQPSK, 1, 1, 10.0, 3.0, 0.0, 1488, 0),
+              (10, po.DBPSK, 2, 1, 2.0, -18.0, -20.0, 930, 0), (8, po.DQPSK, 1, 0, 12.0, -30.0, 0.0, 5000, 1), (10, po.DBPSK, 1, 1, 8.0, 40.0, 38.5, 0, 0),
+              (5, po.DBPSK, 1, 1, 15.0, 0.0, 0.0, 2015, 0), (10, po.DBPSK, 1, 1, -25.0, 0.0, 0.0, 1000, 0),
+              # the ZC search's coarse grid (step 31) can miss the 8-sample main lobe: a reference lock 608 samples early, reproduced as it is
+              (5, po.DBPSK, 1, 1, 15.0, 0.0, 0.0, 2000, 0), (10, po.DQPSK, 2, 1, 4.0, 9.0, 8.0, 3100, 2)]
+
+
+def mcwf_buffer(checker, case, idx):
+    """(info21, buffer): one R1/4 codeword through the plug-in's TX, the simulator's TX CFO, lead / tail silence and the channel"""
+    nc, mod, sp, data_sync, snr, cfo, known, lead, kind = case
+    rng = np.random.default_rng(8300 + idx)
+    info = rng.integers(0, 256, 21, dtype=np.uint8)
+    info[-1] &= 0xC0
+    coded = checker.ldpc_encode(po.R1_4, info)[:81]
+    tx = checker.mcdpsk_wf_tx(nc, mod, po.R1_4, sp, data_sync, coded)
+    tx, _ = checker.apply_tx_cfo(tx, cfo)
+    buf = np.concatenate([np.zeros(lead, np.float32), tx, np.zeros(1024, np.float32)])
+    return info, checker.channel(kind, snr, 9100 + idx, buf)
+
+
+def mcwf_fixture(R):
+    import zlib
+    rec = {"cases": np.array(MCWF_CASES, np.float64)}
+    for i, case in enumerate(MCWF_CASES):
+        nc, mod, sp, data_sync, snr, cfo, known, lead, kind = case
+        info, x = mcwf_buffer(R, case, i)
+        sync4, llr, aux5 = R.mcdpsk_wf_rx(nc, mod, po.R1_4, sp, data_sync, x, known)
+        rec[f"crc_{i}"] = np.uint32(zlib.crc32(x.tobytes())); rec[f"sync_{i}"] = sync4; rec[f"llr_{i}"] = llr; rec[f"aux_{i}"] = aux5
+        dec = np.zeros(23, np.int32)
+        if len(llr) >= 648:
+            ok, out, it, tries = R.robust_decode(po.R1_4, llr[:648])
+            dec[:3] = [int(ok), it, tries]; dec[3:3 + 20] = out[:20]
+        rec[f"dec_{i}"] = dec
+        rec[f"sizes_{i}"] = R.mcdpsk_wf_sizes(nc, mod, po.R1_4, sp, 3)
+        print("mc-dpsk waveform case", i, case, "sync", sync4, "soft", len(llr), "decoded", dec[:3], "payload ok", bool(dec[0]) and np.array_equal(dec[3:23].astype(np.uint8), info[:20]))
+    return rec
+
+
 def main():
     if not po.Ref.available():
         print("needs oracle/_ref/libria_ref.so (make -C oracle ref)")
@@ -437,6 +477,9 @@ def main():
         return 0
     if only == "robust":
         np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
+        return 0
+    if only == "mcwf":
+        np.savez_compressed(os.path.join(OUT, "mcdpsk_waveform.npz"), **mcwf_fixture(R))
         return 0
     if only == "cfo":
         np.savez_compressed(os.path.join(OUT, "cfo_impairment.npz"), **cfo_fixture(R))
@@ -516,6 +559,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "robust_ldpc.npz"), **robust_fixture(R))
     np.savez_compressed(os.path.join(OUT, "harq_trials.npz"), **harq_fixture(R))
     np.savez_compressed(os.path.join(OUT, "cfo_impairment.npz"), **cfo_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "mcdpsk_waveform.npz"), **mcwf_fixture(R))
     print("done ->", OUT)
     return 0
 

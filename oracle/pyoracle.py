@@ -239,6 +239,40 @@ class Oracle:
         self.lib.ro_apply_tx_cfo(fp(x), len(x), cfo_hz, fp(ph), fp(y))
         return y, float(ph[0])
 
+    def mcdpsk_wf_tx(self, carriers, mod, rate, spreading, data_preamble, coded):
+        """MCDPSKWaveform TX restated from the oracle's pieces (mc_dpsk_waveform.cpp:127-174)"""
+        bps = 1 if mod == DBPSK else 2
+        pre = self.zc_generate(5) if data_preamble else self.chirp_generate()
+        return np.concatenate([pre, self.mcdpsk_modulate(carriers, bps, spreading, coded)])
+
+    def mcdpsk_wf_rx(self, carriers, mod, rate, spreading, data_sync, samples, known_cfo=0.0, threshold=None, frame_len=0):
+        """MCDPSKWaveform RX restated (mc_dpsk_waveform.cpp:176-338): detectSync / detectDataSync -> setFrequencyOffset(result
+        CFO) -> process (demodulator after an external chirp detection) -> same tuple as Ref.mcdpsk_wf_rx"""
+        x = np.ascontiguousarray(samples, np.float32)
+        bps = 1 if mod == DBPSK else 2
+        sync4, aux5 = np.zeros(4, np.float32), np.zeros(5, np.float32)
+        if data_sync:
+            r = self.zc_detect(x, 0.2 if threshold is None else threshold, 12, known_cfo)     # roots DATA | CONTROL
+            sync4[:] = [r[0], r[2] if r[0] else -1.0, r[3], r[4]]
+        else:
+            r = self.chirp_detect(x, 0.15 if threshold is None else threshold)
+            sync4[:] = [r[0], (r[2] + 24000 + 4800) if r[0] else r[1], max(r[4], r[5]), r[3]]
+        start = int(sync4[1])
+        if not sync4[0] or start < 0 or start >= len(x):
+            return sync4, np.zeros(0, np.float32), aux5
+        take = len(x) - start
+        if frame_len > 0:
+            take = min(take, frame_len)
+        cfo = float(sync4[3])
+        if data_sync and abs(known_cfo) > 0.01 and abs(np.float32(cfo) - np.float32(known_cfo)) > 1.0:   # streaming_decoder.cpp:903-917
+            cfo = float(np.float32(known_cfo))
+        aux5[3] = cfo
+        if take <= 9 * 512:
+            return sync4, np.zeros(0, np.float32), aux5
+        llr, aux = self.mcdpsk_demod(carriers, bps, spreading, x[start:start + take], cfo, 0.0)
+        aux5[:] = [1.0, aux[0], aux[1], cfo, 1.0]
+        return sync4, llr, aux5
+
     def rx_process(self, mod, rate, samples, cfo_hz=0.0, abs_pos=0, burst_marker=False):
         g = self.geom(mod, rate)
         samples = np.ascontiguousarray(samples, np.float32)
@@ -344,6 +378,10 @@ class Ref:
         L.ref_burst_deinterleave.argtypes = [C.c_int, _f, _f]
         L.ref_channel_cfo.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_float, C.c_float, _f, C.c_int, _f, _f]
         L.ref_apply_tx_cfo.argtypes = [_f, C.c_int, C.c_float, _f, _f]
+        L.ref_mcdpsk_wf_tx.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8, C.c_int, _f, C.c_int]
+        L.ref_mcdpsk_wf_rx.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float, C.c_int, _f, _f, C.c_int, _f]
+        L.ref_mcdpsk_wf_sizes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i]
+        L.ref_mcdpsk_wf_sizes.restype = None
         L.ref_rx_open.argtypes = [C.c_int, C.c_int]
         L.ref_rx_open.restype = C.c_void_p
         L.ref_rx_close.argtypes = [C.c_void_p]
@@ -364,6 +402,28 @@ class Ref:
         ph = np.array([phase], np.float32)
         self.lib.ref_apply_tx_cfo(fp(x), len(x), cfo_hz, fp(ph), fp(y))
         return y, float(ph[0])
+
+    def mcdpsk_wf_tx(self, carriers, mod, rate, spreading, data_preamble, coded):
+        """MCDPSKWaveform: generatePreamble() / generateDataPreamble() + modulate(coded)"""
+        coded = np.ascontiguousarray(coded, np.uint8)
+        out = np.zeros(700000, np.float32)
+        n = self.lib.ref_mcdpsk_wf_tx(carriers, mod, rate, spreading, int(data_preamble), up(coded), len(coded), fp(out), len(out))
+        assert n > 0, n
+        return out[:n].copy()
+
+    def mcdpsk_wf_rx(self, carriers, mod, rate, spreading, data_sync, samples, known_cfo=0.0, threshold=None, frame_len=0):
+        """One MCDPSKWaveform in StreamingDecoder's call order -> (sync4 {detected, start, corr, cfo}, soft bits,
+        aux5 {ready, estimatedCFO, fading index, getFrequencyOffset, isSynced})"""
+        x = np.ascontiguousarray(samples, np.float32)
+        thr = (0.2 if data_sync else 0.15) if threshold is None else threshold
+        sync4, aux5, llr = np.zeros(4, np.float32), np.zeros(5, np.float32), np.zeros(16384, np.float32)
+        n = self.lib.ref_mcdpsk_wf_rx(carriers, mod, rate, spreading, int(data_sync), fp(x), len(x), known_cfo, thr, frame_len, fp(sync4), fp(llr), len(llr), fp(aux5))
+        return sync4, llr[:n].copy(), aux5
+
+    def mcdpsk_wf_sizes(self, carriers, mod, rate, spreading, num_cw):
+        out = np.zeros(4, np.int32)
+        self.lib.ref_mcdpsk_wf_sizes(carriers, mod, rate, spreading, num_cw, ip(out))
+        return out
 
     def rx_open(self, mod, rate):
         """One kept OFDMChirpWaveform (configured once): the per-thread object of the CPU throughput baseline"""

@@ -51,6 +51,7 @@
 #include "waveform/ofdm_chirp_waveform.hpp"
 #include "waveform/ofdm_cox_waveform.hpp"
 #undef private
+#include "waveform/mc_dpsk_waveform.hpp"
 
 using namespace ultra;
 
@@ -690,6 +691,61 @@ int ref_harq_trials(int nc, int bps, int spreading, int kind, float snr_db, cons
         }
     }
     return 0;
+}
+
+// ---------------------------------------------------------------- MC-DPSK plug-in (src/waveform/mc_dpsk_waveform.cpp)
+// The reference's MCDPSKWaveform object itself, driven as gui::StreamingDecoder / StreamingEncoder drive it.
+static std::unique_ptr<MCDPSKWaveform> mc_waveform(int carriers, int mod, int rate, int spreading) {
+    auto wf = std::make_unique<MCDPSKWaveform>(carriers);
+    wf->configure(static_cast<Modulation>(mod), static_cast<CodeRate>(rate));
+    wf->setSpreadingMode(spreading == 4 ? SpreadingMode::TIME_4X : spreading == 2 ? SpreadingMode::TIME_2X : SpreadingMode::NONE);
+    return wf;
+}
+// TX: generatePreamble() (dual chirp + training + reference; data_preamble 0) or generateDataPreamble() (ZC DATA root +
+// training + reference; 1), then modulate(coded)
+int ref_mcdpsk_wf_tx(int carriers, int mod, int rate, int spreading, int data_preamble, const uint8_t* coded, int n_coded, float* out, int max_n) {
+    ref_quiet();
+    auto wf = mc_waveform(carriers, mod, rate, spreading);
+    Samples pre = data_preamble ? wf->generateDataPreamble() : wf->generatePreamble();
+    Samples dat = wf->modulate(Bytes(coded, coded + n_coded));
+    if (static_cast<int>(pre.size() + dat.size()) > max_n) return -static_cast<int>(pre.size() + dat.size());
+    std::memcpy(out, pre.data(), pre.size() * sizeof(float));
+    std::memcpy(out + pre.size(), dat.data(), dat.size() * sizeof(float));
+    return static_cast<int>(pre.size() + dat.size());
+}
+// RX on ONE object: reset() -> detectSync (0) | detectDataSync(known_cfo) (1) -> setFrequencyOffset(sync CFO, host rule below) ->
+// process(span from start_sample, frame_len samples or all that remain) -> getSoftBits
+// (streaming_decoder.cpp:723,733,831,1347-1363).  sync4 = {detected, start_sample, correlation, cfo_hz};
+// aux5 = {process() ready, estimatedCFO(), getFadingIndex(), getFrequencyOffset(), isSynced()}.  Returns the soft-bit count.
+int ref_mcdpsk_wf_rx(int carriers, int mod, int rate, int spreading, int data_sync, const float* samples, int n, float known_cfo,
+                     float threshold, int frame_len, float* sync4, float* llr_out, int max_llr, float* aux5) {
+    ref_quiet();
+    auto wf = mc_waveform(carriers, mod, rate, spreading);
+    wf->reset();
+    SyncResult r;
+    bool ok = data_sync ? wf->detectDataSync(SampleSpan(samples, n), r, known_cfo, threshold) : wf->detectSync(SampleSpan(samples, n), r, threshold);
+    sync4[0] = ok ? 1.0f : 0.0f; sync4[1] = static_cast<float>(r.start_sample); sync4[2] = r.correlation; sync4[3] = r.cfo_hz;
+    for (int i = 0; i < 5; ++i) aux5[i] = 0.0f;
+    if (!ok || r.start_sample < 0 || r.start_sample >= n) return 0;
+    // the host's CFO rule between sync and process (streaming_decoder.cpp:903-917): when connected with an established CFO,
+    // a measurement more than 1 Hz away from it is replaced by the established value
+    float new_cfo = r.cfo_hz;
+    if (data_sync && std::abs(known_cfo) > 0.01f && std::abs(new_cfo - known_cfo) > 1.0f) new_cfo = known_cfo;
+    wf->setFrequencyOffset(new_cfo);
+    int take = n - r.start_sample;
+    if (frame_len > 0 && frame_len < take) take = frame_len;
+    bool ready = wf->process(SampleSpan(samples + r.start_sample, take));
+    std::vector<float> soft = wf->getSoftBits();
+    aux5[0] = ready ? 1.0f : 0.0f; aux5[1] = wf->estimatedCFO(); aux5[2] = wf->getFadingIndex(); aux5[3] = wf->getFrequencyOffset();
+    aux5[4] = wf->isSynced() ? 1.0f : 0.0f;
+    std::memcpy(llr_out, soft.data(), std::min<size_t>(soft.size(), max_llr) * sizeof(float));
+    return static_cast<int>(soft.size());
+}
+// sizing queries of the object: out4 = {getMinSamplesForFrame, getMinSamplesForCWCount(num_cw), getDataPreambleSamples, getPreambleSamples}
+void ref_mcdpsk_wf_sizes(int carriers, int mod, int rate, int spreading, int num_cw, int* out4) {
+    ref_quiet();
+    auto wf = mc_waveform(carriers, mod, rate, spreading);
+    out4[0] = wf->getMinSamplesForFrame(); out4[1] = wf->getMinSamplesForCWCount(num_cw); out4[2] = wf->getDataPreambleSamples(); out4[3] = wf->getPreambleSamples();
 }
 
 // ---------------------------------------------------------------- burst chain

@@ -1303,6 +1303,61 @@ int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, c
     return RIA_OK;
 }
 
+// Host-buffer forms for the single-frame MC-DPSK plug-in adaptor (GpuMcDpskWaveform): staged through the handle's pinned +
+// device block on the handle's own stream, like ria_gpu_rx_frames_host.
+int ria_gpu_mcdpsk_demod_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const float* samples_host, int n_samples, float cfo_hz,
+                              float phase0, float* llr_out_host, int max_llr, ria_mcdpsk_status* status_out) {
+    if (!h || !mcdpsk_config_ok(cfg) || !samples_host || !llr_out_host || !status_out || n_samples < (kMcTrain + 2) * kMcSps)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_demod_host: bad arguments");
+    const int num_rx = (n_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
+    const int n_llr = std::max(1, num_rx / cfg->spreading) * cfg->num_carriers * cfg->bits_per_symbol;
+    if (max_llr < n_llr) return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_demod_host: llr buffer too small (%d needed)", n_llr);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t b_s = static_cast<size_t>(n_samples) * sizeof(float), o_par = up256(b_s), o_llr = up256(o_par + 8);
+    const size_t o_st = up256(o_llr + static_cast<size_t>(n_llr) * sizeof(float)), total = up256(o_st + sizeof(ria_mcdpsk_status));
+    int rc = ensure_host_stage(h, total);
+    if (rc != RIA_OK) return rc;
+    unsigned char *D = h->d_hstage, *P = h->p_hstage;
+    hipStream_t s = h->hstream;
+    std::memcpy(P, samples_host, b_s);
+    const float par[2] = {cfo_hz, phase0};
+    std::memcpy(P + o_par, par, sizeof(par));
+    HIP_TRY(h, hipMemcpyAsync(D, P, o_par + 8, hipMemcpyHostToDevice, s));
+    rc = ria_gpu_mcdpsk_demod_batch(h, cfg, reinterpret_cast<const float*>(D), n_samples, n_samples, 1, reinterpret_cast<const float*>(D + o_par),
+                                    reinterpret_cast<const float*>(D + o_par) + 1, reinterpret_cast<float*>(D + o_llr), n_llr,
+                                    reinterpret_cast<ria_mcdpsk_status*>(D + o_st), s);
+    if (rc != RIA_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(P + o_llr, D + o_llr, total - o_llr, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::memcpy(llr_out_host, P + o_llr, static_cast<size_t>(n_llr) * sizeof(float));
+    std::memcpy(status_out, P + o_st, sizeof(ria_mcdpsk_status));
+    return RIA_OK;
+}
+
+int ria_gpu_ldpc_decode_robust_host(ria_gpu_handle h, const float* llr_host, int n_cw, uint8_t* out_host, uint8_t* ok_host,
+                                    uint16_t* iters_host, uint8_t* tries_host) {
+    if (!h || !llr_host || !out_host || !ok_host || n_cw <= 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_ldpc_decode_robust_host: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = static_cast<size_t>(n_cw), nb = static_cast<size_t>((h->geo.info_bits + 7) / 8);
+    const size_t b_llr = n * 648 * sizeof(float), o_out = up256(b_llr), o_ok = up256(o_out + n * nb), o_it = up256(o_ok + n), o_tr = up256(o_it + 2 * n);
+    const size_t total = up256(o_tr + n);
+    int rc = ensure_host_stage(h, total);
+    if (rc != RIA_OK) return rc;
+    unsigned char *D = h->d_hstage, *P = h->p_hstage;
+    hipStream_t s = h->hstream;
+    std::memcpy(P, llr_host, b_llr);
+    HIP_TRY(h, hipMemcpyAsync(D, P, b_llr, hipMemcpyHostToDevice, s));
+    rc = ria_gpu_ldpc_decode_robust_batch(h, reinterpret_cast<const float*>(D), n_cw, D + o_out, D + o_ok, reinterpret_cast<uint16_t*>(D + o_it), D + o_tr, s);
+    if (rc != RIA_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(P + o_out, D + o_out, total - o_out, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::memcpy(out_host, P + o_out, n * nb);
+    std::memcpy(ok_host, P + o_ok, n);
+    if (iters_host) std::memcpy(iters_host, P + o_it, 2 * n);
+    if (tries_host) std::memcpy(tries_host, P + o_tr, n);
+    return RIA_OK;
+}
+
 int ria_gpu_mcdpsk_modulate_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data, int n_bytes,
                                  float* out_host, int max_n) {
     if (!h || !mcdpsk_config_ok(cfg) || !data || !out_host || n_bytes < 0) return RIA_ERR_INVALID;

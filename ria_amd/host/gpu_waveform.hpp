@@ -12,6 +12,7 @@
 // failed call throws std::runtime_error from the constructor / returns false / decoded[i]=false
 // exactly where the reference would.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -219,6 +220,173 @@ public:
 private:
     float noise_floor_ = 0.0f;
 };
+
+// MC-DPSK: the low-SNR plug-in (src/waveform/mc_dpsk_waveform.cpp; SURVEY.md 2 row 7, configs 1 and 5's low rungs).
+// Mirrors ultra::MCDPSKWaveform: 3..20 carriers, DBPSK / DQPSK, 1x / 2x / 4x time spreading, dual-chirp acquisition for
+// PING / PONG (detectSync), Zadoff-Chu acquisition for connected DATA / CONTROL frames (detectDataSync), and the demodulator
+// driven as after an external chirp detection (process).  Every call runs on the GPU through the C ABI; there is no CPU
+// fallback.  The library handle is bound to the codeword rate the host decodes MC-DPSK codewords with (R1/4 by default).
+enum class SpreadingMode : uint8_t { NONE = 0, TIME_2X = 1, TIME_4X = 2 };        // multi_carrier_dpsk.hpp:27-31
+class GpuMcDpskWaveform /* : public ultra::IWaveform on the reference side */ {
+public:
+    explicit GpuMcDpskWaveform(int num_carriers = 8, int device = 0) : device_(device) {   // mc_dpsk_waveform.cpp:10-19
+        num_carriers_ = std::max(3, std::min(20, num_carriers));
+        gpu_ = std::make_unique<GpuHandle>(Modulation::DQPSK, CodeRate::R1_4, device_);
+    }
+    std::string getName() const { return "MC-DPSK (MI355X)"; }
+    // configure(): DBPSK / DQPSK / D8PSK are accepted, anything else becomes DQPSK (mc_dpsk_waveform.cpp:80-112).  The GPU
+    // demodulator implements 1 and 2 bits per symbol; with D8PSK (3 bits, not on the reference's ladder) process() fails loudly.
+    void configure(Modulation mod, CodeRate rate) {
+        modulation_ = (mod == Modulation::DQPSK || mod == Modulation::DBPSK || mod == Modulation::D8PSK) ? mod : Modulation::DQPSK;
+        code_rate_ = rate;
+        bits_per_symbol_ = (mod == Modulation::DBPSK) ? 1 : (mod == Modulation::D8PSK) ? 3 : 2;
+        initComponents();
+    }
+    void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; demod_cfo_ = cfo_hz; }     // :114-119 (demodulator_->setCFO)
+    void setCarrierCount(int carriers) { num_carriers_ = std::max(3, std::min(20, carriers)); initComponents(); }   // :418-421
+    void setSpreadingMode(SpreadingMode mode) { spreading_ = mode; initComponents(); }        // :423-430
+    SpreadingMode getSpreadingMode() const { return spreading_; }
+    Modulation getModulation() const { return modulation_; }
+    CodeRate getCodeRate() const { return code_rate_; }
+    float getFrequencyOffset() const { return cfo_hz_; }
+    bool supportsDataPreamble() const { return true; }
+
+    // ---- TX (bit-identical audio; used by tests and simulators)
+    std::vector<float> generatePreamble() {                 // dual chirp + training + reference (multi_carrier_dpsk.hpp:126-139)
+        std::vector<float> out(57600);
+        int n = ria_gpu_chirp_preamble(gpu_->get(), out.data(), static_cast<int>(out.size()));
+        out.resize(n > 0 ? static_cast<size_t>(n) : 0);
+        std::vector<float> tr = trainingAndReference();
+        out.insert(out.end(), tr.begin(), tr.end());
+        return out;
+    }
+    std::vector<float> generateDataPreamble() {             // ZC (DATA root) + training + reference (mc_dpsk_waveform.cpp:136-167)
+        std::vector<float> out(4096);
+        int n = ria_gpu_zc_preamble(gpu_->get(), 5, out.data(), static_cast<int>(out.size()));
+        out.resize(n > 0 ? static_cast<size_t>(n) : 0);
+        std::vector<float> tr = trainingAndReference();
+        out.insert(out.end(), tr.begin(), tr.end());
+        return out;
+    }
+    std::vector<float> modulate(const Bytes& encoded) {     // data symbols only (MultiCarrierDPSKModulator::modulate)
+        std::vector<float> all = modulateAll(encoded);
+        const size_t skip = static_cast<size_t>(9 * 512);
+        return all.size() > skip ? std::vector<float>(all.begin() + skip, all.end()) : std::vector<float>();
+    }
+
+    // ---- RX
+    // detectSync(): dual-chirp detection; start_sample = first TRAINING sample, from the down chirp (mc_dpsk_waveform.cpp:176-225)
+    bool detectSync(SampleSpan samples, SyncResult& result, float threshold = 0.15f) {
+        ria_chirp_result r{};
+        if (ria_gpu_sync_host(gpu_->get(), 0, samples.data(), static_cast<int>(samples.size()), threshold, 0.0f, 0u, &r) != RIA_OK) return false;
+        result.detected = r.success != 0;
+        result.start_sample = r.up_chirp_start;
+        result.correlation = std::max(r.up_correlation, r.down_correlation);
+        result.cfo_hz = r.cfo_hz;
+        result.has_training = true;
+        if (r.success) {
+            synced_ = true; last_cfo_ = r.cfo_hz;
+            result.start_sample = r.down_chirp_start + 24000 + 4800;
+        }
+        return result.detected;
+    }
+    // detectDataSync(): ZC preamble of connected DATA / CONTROL frames, roots DATA | CONTROL only, the receiver's known CFO
+    // mixed out first; the reported CFO is the residual, the object's own estimate known + residual (mc_dpsk_waveform.cpp:227-292)
+    bool detectDataSync(SampleSpan samples, SyncResult& result, float known_cfo_hz = 0.0f, float threshold = 0.2f) {
+        if (std::fabs(known_cfo_hz) > 0.1f) setFrequencyOffset(known_cfo_hz);
+        ria_zc_result r{};
+        constexpr uint32_t DATA_CONTROL_ROOTS = (1u << 2) | (1u << 3);      // ZC_ROOT_MASK_DATA | ZC_ROOT_MASK_CONTROL
+        if (ria_gpu_sync_host(gpu_->get(), 2, samples.data(), static_cast<int>(samples.size()), threshold, known_cfo_hz, DATA_CONTROL_ROOTS, &r) != RIA_OK)
+            return false;
+        result.detected = r.detected != 0;
+        result.correlation = r.correlation;
+        result.cfo_hz = r.cfo_hz;
+        result.has_training = true;
+        if (r.detected) {
+            synced_ = true; connected_ = true;
+            result.start_sample = r.start_sample;
+            last_cfo_ = (std::fabs(known_cfo_hz) > 0.1f) ? known_cfo_hz + r.cfo_hz : r.cfo_hz;
+            cfo_hz_ = last_cfo_;
+        }
+        return result.detected;
+    }
+    // process(): samples = training (8 x 512) + reference (512) + data; demodulator in its "chirp detected externally" state
+    // with the object's CFO (mc_dpsk_waveform.cpp:294-338 -> multi_carrier_dpsk.hpp:797-895).  false = not enough samples yet.
+    bool process(SampleSpan samples) {
+        soft_bits_.clear();
+        demod_cfo_ = cfo_hz_;                               // setChirpDetected(cfo_hz_)
+        const size_t preamble = 9 * 512;
+        if (samples.size() <= preamble) return false;       // the demodulator waits for at least one codeword of data
+        if (bits_per_symbol_ == 3) throw std::runtime_error("GpuMcDpskWaveform: 3 bits per symbol (D8PSK) is not implemented on the GPU path");
+        if (samples.size() < preamble + 512) return false;  // less than one data symbol: nothing to demodulate
+        ria_mcdpsk_config cfg{num_carriers_, bits_per_symbol_, spreadingFactor(), 0};
+        const int n = static_cast<int>(samples.size());
+        const int max_llr = std::max(1, ((n - 9 * 512) / 512) / spreadingFactor()) * num_carriers_ * bits_per_symbol_;
+        std::vector<float> llr(static_cast<size_t>(max_llr));
+        ria_mcdpsk_status st{};
+        if (ria_gpu_mcdpsk_demod_host(gpu_->get(), &cfg, samples.data(), n, cfo_hz_, 0.0f, llr.data(), max_llr, &st) != RIA_OK) return false;
+        llr.resize(static_cast<size_t>(st.n_llr));
+        soft_bits_ = std::move(llr);
+        demod_cfo_ = st.cfo_hz; fading_index_ = st.fading_index;
+        synced_ = true;
+        return true;
+    }
+    std::vector<float> getSoftBits() { return std::move(soft_bits_); }
+    void reset() { soft_bits_.clear(); synced_ = false; }   // CFO preserved (mc_dpsk_waveform.cpp:344-352)
+    bool isSynced() const { return synced_; }
+    bool hasData() const { return !soft_bits_.empty(); }
+    float estimatedSNR() const { return last_snr_; }
+    float estimatedCFO() const { return demod_cfo_; }       // demodulator_->getEstimatedCFO()
+    float getFadingIndex() const { return fading_index_; }
+    bool isFading() const { return fading_index_ > 0.65f; }
+    int getCarrierCount() const { return num_carriers_; }
+    int getSamplesPerSymbol() const { return 512; }
+    int getPreambleSamples() const { return 2 * 24000 + 2 * 4800; }                        // chirp_sync_->getTotalSamples()
+    int getDataPreambleSamples() const { return 2512 + 8 * 512 + 512; }                     // :405-416
+    int getMinSamplesForFrame() const { return getMinSamplesForCWCount(1); }                // :432-455
+    int getMinSamplesForCWCount(int num_cw) const {                                         // :457-475
+        const int bits_per_symbol = num_carriers_ * bits_per_symbol_;
+        const int data_symbols_per_cw = (648 + bits_per_symbol - 1) / bits_per_symbol;
+        return 8 * 512 + 512 + num_cw * data_symbols_per_cw * 512 * spreadingFactor();
+    }
+    GpuHandle& handle() { return *gpu_; }
+
+private:
+    int spreadingFactor() const { return spreading_ == SpreadingMode::TIME_4X ? 4 : spreading_ == SpreadingMode::TIME_2X ? 2 : 1; }
+    void initComponents() { soft_bits_.clear(); demod_cfo_ = 0.0f; fading_index_ = 0.0f; }  // a fresh demodulator; cfo_hz_ and synced_ are the waveform's own
+    std::vector<float> modulateAll(const Bytes& encoded) {
+        if (bits_per_symbol_ == 3) throw std::runtime_error("GpuMcDpskWaveform: D8PSK is not implemented on the GPU path");
+        ria_mcdpsk_config cfg{num_carriers_, bits_per_symbol_, spreadingFactor(), 0};
+        std::vector<float> out(static_cast<size_t>(9 * 512) + (encoded.size() * 8 + 1) * 512 * 4);
+        static const uint8_t none = 0;
+        int n = ria_gpu_mcdpsk_modulate_host(gpu_->get(), &cfg, encoded.empty() ? &none : encoded.data(), static_cast<int>(encoded.size()), out.data(),
+                                             static_cast<int>(out.size()));
+        out.resize(n > 0 ? static_cast<size_t>(n) : 0);
+        return out;
+    }
+    std::vector<float> trainingAndReference() { std::vector<float> a = modulateAll(Bytes()); a.resize(std::min<size_t>(a.size(), 9 * 512)); return a; }
+
+    int device_;
+    int num_carriers_ = 8, bits_per_symbol_ = 2;
+    SpreadingMode spreading_ = SpreadingMode::NONE;
+    Modulation modulation_ = Modulation::DQPSK;
+    CodeRate code_rate_ = CodeRate::R1_4;
+    std::unique_ptr<GpuHandle> gpu_;
+    std::vector<float> soft_bits_;
+    float cfo_hz_ = 0.0f, last_cfo_ = 0.0f, last_snr_ = 0.0f, demod_cfo_ = 0.0f, fading_index_ = 0.0f;
+    bool synced_ = false, connected_ = false;
+};
+
+// robustDecodeSingleCW(llr, 648, rate) (streaming_decoder.cpp:1028-1058): the per-codeword decoder of the MC-DPSK and
+// control-frame paths - min-sum factor 0.9375, then 0.875 / 0.75 / 0.625 / 0.5 - on the GPU.  `gpu` must be bound to `rate`.
+inline std::pair<bool, Bytes> robustDecodeSingleCW(GpuHandle& gpu, const float* llr648, int* tries = nullptr) {
+    const int nb = (gpu.geo().info_bits + 7) / 8;
+    Bytes out(static_cast<size_t>(nb));
+    uint8_t ok = 0, tr = 0;
+    if (ria_gpu_ldpc_decode_robust_host(gpu.get(), llr648, 1, out.data(), &ok, nullptr, &tr) != RIA_OK) return {false, Bytes()};
+    if (tries) *tries = tr;
+    return {ok != 0, ok ? out : Bytes()};
+}
 
 // protocol::v2::decodeFixedFrame(interleaved_soft, rate, use_channel_deinterleave, bits_per_symbol)
 // (frame_v2.hpp:848).  `wf` supplies the configured handle (rate and bits_per_symbol must match it).

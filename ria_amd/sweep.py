@@ -246,7 +246,7 @@ def run_ladder_chunk(engines, point, base_seed, point_index, start, n, max_tx=4,
 #
 # Every buffer is built ON THE DEVICE by the library's reference-identical impairments, from a recipe that is a
 # function of global identifiers only (seed, grid point, kind, global preamble index), so that (a) a CPU checker can
-# rebuild the very same buffer from the recipe (oracle/pyoracle.py: acq_buffer) and compare every sample and every
+# rebuild the very same buffer from the recipe (the tests do, with the CPU checker) and compare every sample and every
 # detector field bit for bit, and (b) the counters do not depend on chunking or on the number of GPUs:
 #   preamble (ria_gpu_zc_preamble / ria_gpu_chirp_preamble, the reference generators' audio)
 #   -> cfo_model "tx":        SimulatedChannel::applyTxCFO of the transmission (tools/cli_simulator.cpp:298-341, the

@@ -18,6 +18,81 @@ int main(int argc, char** argv) {
     std::vector<float> x(1 << 20);
     x.resize(fread(x.data(), 4, x.size(), f));
     fclose(f);
+    if (argc > 8 && (atoi(argv[7]) == 4 || atoi(argv[7]) == 5)) {
+        // MC-DPSK plug-in in gui::StreamingDecoder's order on ONE object (streaming_decoder.cpp:723,733,831,903-917,1347-1363):
+        // configure / setSpreadingMode -> reset -> detectSync | detectDataSync(known CFO) -> setFrequencyOffset(sync CFO, with the
+        // host's "trust the established CFO" rule) -> process(from start_sample) -> getSoftBits -> robustDecodeSingleCW.
+        // argv: <modulation> <carriers> <buffer.f32> <known_cfo> <spreading> <out_prefix> 4 <data_sync>
+        const int carriers = atoi(argv[2]), spreading = atoi(argv[5]);
+        GpuMcDpskWaveform wf(carriers);
+        wf.configure(mod, CodeRate::R1_4);
+        wf.setSpreadingMode(spreading == 4 ? SpreadingMode::TIME_4X : spreading == 2 ? SpreadingMode::TIME_2X : SpreadingMode::NONE);
+        std::string p = argv[6];
+        if (atoi(argv[7]) == 5) {
+            // HARQ chain of one data codeword (streaming_decoder.cpp:2758-2800): argv[8] receptions of equal length back to back in
+            // the file, each training + reference + data: robust decode of the fresh soft bits; on failure ChaseCache::store
+            // (first reception copies, later ones add) and, from the second reception on, robust decode of the sum
+            const int n_rx = atoi(argv[8]);
+            const size_t len = x.size() / static_cast<size_t>(n_rx);
+            std::vector<float> acc; int combines = 0;
+            for (int t = 0; t < n_rx; ++t) {
+                wf.reset();
+                wf.setFrequencyOffset(0.0f);
+                if (!wf.process(SampleSpan{x.data() + t * len, len})) return 5;
+                std::vector<float> soft = wf.getSoftBits();
+                if (soft.size() < 648) return 6;
+                soft.resize(648);
+                int tries = 0, tries2 = 0;
+                auto res = robustDecodeSingleCW(wf.handle(), soft.data(), &tries);
+                if (!res.first) {
+                    if (combines == 0) acc = soft; else for (size_t i = 0; i < 648; ++i) acc[i] += soft[i];   // chase_cache.cpp:27-88
+                    ++combines;
+                    if (combines > 1) res = robustDecodeSingleCW(wf.handle(), acc.data(), &tries2);
+                }
+                printf("%d %d %d %d %.9g", t + 1, res.first ? 1 : 0, tries, tries2, wf.getFadingIndex());
+                if (res.first) for (int b = 0; b < 20; ++b) printf(" %u", res.second[b]);
+                printf("\n");
+                if (res.first) break;
+            }
+            return 0;
+        }
+        printf("%d %d %d %d\n", wf.getMinSamplesForFrame(), wf.getMinSamplesForCWCount(3), wf.getDataPreambleSamples(), wf.getPreambleSamples());
+        {   // TX side of the plug-in: FNV-1a over the audio bytes of both preambles followed by modulate(bytes 0..80)
+            Bytes coded(81);
+            for (int i = 0; i < 81; ++i) coded[i] = static_cast<uint8_t>(i * 37 + 11);
+            for (int which = 0; which < 2; ++which) {
+                std::vector<float> a = which ? wf.generateDataPreamble() : wf.generatePreamble();
+                std::vector<float> d = wf.modulate(coded);
+                a.insert(a.end(), d.begin(), d.end());
+                uint64_t hsh = 1469598103934665603ull;
+                const unsigned char* b = reinterpret_cast<const unsigned char*>(a.data());
+                for (size_t i = 0; i < a.size() * 4; ++i) { hsh ^= b[i]; hsh *= 1099511628211ull; }
+                printf("%zu %llu\n", a.size(), static_cast<unsigned long long>(hsh));
+            }
+        }
+        wf.reset();
+        const float known = static_cast<float>(atof(argv[4]));
+        const bool data_sync = atoi(argv[8]) != 0;
+        SyncResult r;
+        bool ok = data_sync ? wf.detectDataSync(SampleSpan{x.data(), x.size()}, r, known, 0.2f) : wf.detectSync(SampleSpan{x.data(), x.size()}, r, 0.15f);
+        printf("%d %d %.9g %.9g\n", ok ? 1 : 0, r.start_sample, r.correlation, r.cfo_hz);
+        if (!ok || r.start_sample < 0 || static_cast<size_t>(r.start_sample) >= x.size()) return 0;
+        float new_cfo = r.cfo_hz;
+        if (data_sync && std::abs(known) > 0.01f && std::abs(new_cfo - known) > 1.0f) new_cfo = known;
+        wf.setFrequencyOffset(new_cfo);
+        bool ready = wf.process(SampleSpan{x.data() + r.start_sample, x.size() - static_cast<size_t>(r.start_sample)});
+        std::vector<float> soft = wf.getSoftBits();
+        printf("%d %zu %.9g %.9g %.9g %d\n", ready ? 1 : 0, soft.size(), wf.estimatedCFO(), wf.getFadingIndex(), wf.getFrequencyOffset(), wf.isSynced() ? 1 : 0);
+        FILE* o = fopen((p + ".llr").c_str(), "wb"); fwrite(soft.data(), 4, soft.size(), o); fclose(o);
+        if (soft.size() >= 648) {
+            int tries = 0;
+            auto res = robustDecodeSingleCW(wf.handle(), soft.data(), &tries);
+            printf("%d %d", res.first ? 1 : 0, tries);
+            if (res.first) for (int b = 0; b < 20; ++b) printf(" %u", res.second[b]);
+            printf("\n");
+        }
+        return 0;
+    }
     GpuOfdmChirpWaveform rx(mod, rate);
     GpuHandle dec(mod, rate);
     rx.reset();

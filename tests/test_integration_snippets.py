@@ -17,10 +17,11 @@ def snippets():
     return [b for b in blocks if re.match(r"// src/\S+\s+\(new file in the reference\)", b)]
 
 
-def test_integration_md_holds_both_bindings():
+def test_integration_md_holds_all_bindings():
     s = snippets()
-    assert len(s) == 2
+    assert len(s) == 3
     assert "class GpuOFDMChirpWaveform : public OFDMChirpWaveform" in s[0] and "gpuDecodeFixedFrame" in s[1]
+    assert "class GpuMCDPSKWaveform : public MCDPSKWaveform" in s[2]
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference sources not present on this box")
@@ -36,7 +37,9 @@ static ultra::IWaveform* as_interface(const ultra::ModemConfig& c) { return make
 static ultra::protocol::v2::CodewordStatus dec(ria_gpu_handle h, const std::vector<float>& s) {
     return ultra::protocol::v2::gpuDecodeFixedFrame(h, s, ultra::CodeRate::R1_2, true, 188);
 }
-int main() { (void)&as_interface; (void)&dec; return 0; }
+static ultra::IWaveform* mc_as_interface() { return new ultra::GpuMCDPSKWaveform(10); }
+static std::pair<bool, ria_host::Bytes> robust(ultra::GpuMCDPSKWaveform& w, const float* llr) { return ria_host::robustDecodeSingleCW(w.decoderHandle(), llr); }
+int main() { (void)&as_interface; (void)&dec; (void)&mc_as_interface; (void)&robust; return 0; }
 """)
     cmd = ["g++", "-std=c++20", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter",
            "-I" + os.path.join(REF, "include"), "-I" + os.path.join(REF, "src"), "-I" + os.path.join(REF, "src", "waveform"),

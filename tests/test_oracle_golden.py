@@ -418,3 +418,37 @@ def test_config4_grid_oracle_matches_reference_golden(oracle, golden):
         assert bits_equal(got, ref), (kind, gi, cfo, snr, got, ref)
         n_zc += int(kind == "zc" and ref[0]); n_ch += int(kind == "chirp" and ref[0])
     assert n_zc >= 15 and n_ch >= 15
+
+
+# ---- the MC-DPSK plug-in object (src/waveform/mc_dpsk_waveform.cpp) -------------------------------------------------------
+def mcwf_cases(golden, checker):
+    """[(case tuple, info21, buffer, recorded sync4 / soft bits / aux5 / decode record / sizes)]: the buffers are rebuilt from the
+    recipe of oracle/gen_golden.py (mcwf_buffer) and must have the recorded checksums"""
+    import zlib
+    import gen_golden as G
+    g = golden("mcdpsk_waveform")
+    out = []
+    for i, case in enumerate(G.MCWF_CASES):
+        assert tuple(g["cases"][i]) == tuple(float(v) for v in case)
+        info, x = G.mcwf_buffer(checker, case, i)
+        assert zlib.crc32(x.tobytes()) == int(g[f"crc_{i}"]), i
+        out.append((case, info, x, g[f"sync_{i}"], g[f"llr_{i}"], g[f"aux_{i}"], g[f"dec_{i}"], g[f"sizes_{i}"]))
+    return out
+
+
+def test_mcdpsk_waveform_oracle_matches_reference_golden(oracle, golden):
+    """MCDPSKWaveform in StreamingDecoder's order (detectSync | detectDataSync -> setFrequencyOffset -> process -> getSoftBits
+    -> robustDecodeSingleCW) restated from the oracle's pieces vs records taken from the reference's own class: dual-chirp and ZC
+    acquisition, transmitter CFO, known CFO, 1x / 2x / 4x spreading, 5 / 8 / 10 carriers, a missed and a misplaced lock"""
+    n_ok = 0
+    for case, info, x, sync4, llr, aux5, dec, sizes in mcwf_cases(golden, oracle):
+        nc, mod, sp, data_sync, snr, cfo, known, lead, kind = case
+        s4, l, a5 = oracle.mcdpsk_wf_rx(nc, mod, po.R1_4, sp, data_sync, x, known)
+        assert bits_equal(s4, sync4), (case, s4, sync4)
+        assert bits_equal(l, llr), case
+        assert bits_equal(a5, aux5), (case, a5, aux5)
+        if len(l) >= 648:
+            ok, out, it, tries = oracle.robust_decode(po.R1_4, l[:648])
+            assert [int(ok), it, tries] == list(dec[:3]) and np.array_equal(out[:20], dec[3:23].astype(np.uint8)), case
+            n_ok += int(ok and np.array_equal(out[:20], info[:20]))
+    assert n_ok >= 7
