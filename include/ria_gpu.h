@@ -210,7 +210,9 @@ int ria_gpu_channel_batch(ria_gpu_handle h, int kind, float snr_db, uint64_t see
  * (zc_sync.hpp:192-391) for n_buffers capture buffers of buf_len samples each (buffer b starts at
  * samples_dev + b*stride).  root_mask bits 0..3 = PING/PONG/DATA/CONTROL roots 1/3/5/7 (ZC_ROOT_MASK_*).
  * known_cfo_dev: per-buffer known CFO in Hz, or NULL for 0.  Results are bit-identical to the reference's
- * ZCSyncResult for every field (snr_estimate included).  buf_len <= 16384. */
+ * ZCSyncResult for every field (snr_estimate included).  buf_len <= 1048576: buffers up to 16384 samples are mixed down
+ * into the workgroup's LDS (the batched acquisition sweeps), longer ones (the host's connected-mode search windows of
+ * 31 000 - 48 000 samples, streaming_decoder.cpp:424-431) into a device workspace the handle keeps. */
 typedef struct ria_zc_result {
     int32_t detected;        /* ZCSyncResult::detected */
     int32_t frame_type;      /* ZCFrameType: 0 PING 1 PONG 2 DATA 3 CONTROL 255 UNKNOWN */

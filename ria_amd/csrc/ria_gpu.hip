@@ -52,6 +52,7 @@ struct ria_gpu {
     int ch_chunk = 0, ch_outer = 0;
     // transmitter-CFO impairment (cfo_kernels.hip.h): two complex arrays + the phase table, grown on demand
     void* d_txcfo_ws = nullptr; size_t txcfo_ws_bytes = 0;
+    void* d_zc_ws = nullptr; size_t zc_ws_bytes = 0;   // baseband workspace of the long-buffer ZC search
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
     std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
@@ -408,7 +409,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
-    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws, h->d_txcfo_ws}) if (p) (void)hipFree(p);
+    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws, h->d_txcfo_ws, h->d_zc_ws}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c, (void*)h->d_overflow}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
@@ -943,18 +944,36 @@ int ria_gpu_sync_zc_batch(ria_gpu_handle h, const float* samples_dev, int64_t st
                           void* stream) {
     if (!h) return RIA_ERR_INVALID;
     if (n_buffers == 0) return RIA_OK;
-    if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || buf_len > 16384 || stride < buf_len)
+    if (!samples_dev || !out_dev || n_buffers < 0 || buf_len < 0 || buf_len > kZcMaxBuf || stride < buf_len)
         return fail(h, RIA_ERR_INVALID, "ria_gpu_sync_zc_batch: bad arguments");
     ZcArgs A{};
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.n_buffers = n_buffers; A.threshold = threshold;
     A.root_mask = root_mask & 15u; A.known_cfo = known_cfo_dev; A.ref = static_cast<const float2*>(h->d_zc_ref); A.out = out_dev;
-    const int lds = buf_len * static_cast<int>(sizeof(float2)) + 4 * static_cast<int>(sizeof(ZcRootOut));
     HIP_TRY(h, hipSetDevice(h->device));
-    if (lds > h->zc_lds_opted) {   // the opt-in is a per-device attribute: kept per handle (= per device), not per process
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(zc_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        h->zc_lds_opted = lds;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (buf_len <= kZcLdsBuf) {   // the mixed-down buffer fits one workgroup's LDS
+        const int lds = buf_len * static_cast<int>(sizeof(float2)) + 4 * static_cast<int>(sizeof(ZcRootOut));
+        if (lds > h->zc_lds_opted) {   // the opt-in is a per-device attribute: kept per handle (= per device), not per process
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(zc_detect_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            h->zc_lds_opted = lds;
+        }
+        hipLaunchKernelGGL(zc_detect_kernel<true>, dim3(n_buffers), dim3(256), lds, s, A);
+    } else {                      // long search windows: baseband in a global workspace, chunks of buffers under 256 MiB
+        const size_t per = static_cast<size_t>(buf_len) * sizeof(float2);
+        const int chunk = static_cast<int>(std::min<size_t>(n_buffers, std::max<size_t>(1, (size_t(256) << 20) / per)));
+        if (per * chunk > h->zc_ws_bytes) {
+            if (h->d_zc_ws) { HIP_TRY(h, hipStreamSynchronize(s)); (void)hipFree(h->d_zc_ws); }
+            h->d_zc_ws = nullptr; h->zc_ws_bytes = 0;
+            HIP_TRY(h, hipMalloc(&h->d_zc_ws, per * chunk));
+            h->zc_ws_bytes = per * chunk;
+        }
+        A.bb_ws = static_cast<float2*>(h->d_zc_ws);
+        for (int first = 0; first < n_buffers; first += chunk) {
+            A.samples = samples_dev + static_cast<int64_t>(first) * stride; A.n_buffers = std::min(chunk, n_buffers - first);
+            A.known_cfo = known_cfo_dev ? known_cfo_dev + first : nullptr; A.out = out_dev + first;
+            hipLaunchKernelGGL(zc_detect_kernel<false>, dim3(A.n_buffers), dim3(256), 4 * static_cast<int>(sizeof(ZcRootOut)), s, A);
+        }
     }
-    hipLaunchKernelGGL(zc_detect_kernel, dim3(n_buffers), dim3(256), lds, static_cast<hipStream_t>(stream), A);
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }

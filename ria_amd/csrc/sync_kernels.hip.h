@@ -22,6 +22,7 @@
 namespace ria {
 
 constexpr int kZcN = 127, kZcUp = 8, kZcRep = kZcN * kZcUp, kZcGap = 480, kZcPreamble = 2 * kZcRep + kZcGap;
+constexpr int kZcLdsBuf = 16384, kZcMaxBuf = 1 << 20;   // longest buffer mixed down into LDS / longest buffer at all
 
 struct ZcArgs {
     const float* samples;      // [n_buffers][stride]
@@ -33,6 +34,7 @@ struct ZcArgs {
     const float* known_cfo;    // [n_buffers] or null
     const float2* ref;         // [4][1016] interpolated ZC reference per root (host_tables.hpp build_zc_reference)
     ria_zc_result* out;
+    float2* bb_ws;             // [n_buffers][buf_len] baseband workspace of the long-buffer form (kLds = false)
 };
 
 struct ZcRootOut { float combined; int timing; int has_cfo; float cfo; };
@@ -65,10 +67,14 @@ __device__ inline ZcSum zc_corr_at(const float2* __restrict__ bb, const float2* 
     return {sr, si, e};
 }
 
+// kLds: the mixed-down buffer lives in LDS (buffers up to ~19 000 samples: the batched acquisition sweeps); otherwise in a
+// global workspace served by L1 / L2 (the host's connected-mode search windows: 31 000 - 48 000 samples,
+// streaming_decoder.cpp:424-431).  Same arithmetic, same order.
+template <bool kLds>
 __global__ __launch_bounds__(256) void zc_detect_kernel(ZcArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* bb = reinterpret_cast<float2*>(smem);
-    ZcRootOut* ro = reinterpret_cast<ZcRootOut*>(smem + static_cast<size_t>(A.buf_len) * sizeof(float2));
+    float2* bb = kLds ? reinterpret_cast<float2*>(smem) : A.bb_ws + static_cast<size_t>(blockIdx.x) * A.buf_len;
+    ZcRootOut* ro = reinterpret_cast<ZcRootOut*>(smem + (kLds ? static_cast<size_t>(A.buf_len) * sizeof(float2) : 0));
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = A.buf_len;

@@ -278,9 +278,11 @@ def test_zc_sync_matches_oracle_random_buffers(oracle):
     e = engine("QAM16", "R1_2")
     rng = np.random.default_rng(31337)
     pre = {root: oracle.zc_generate(root) for root in (1, 3, 5, 7)}
-    for buf_len in (4512, 3000, 1016, 1500, 900, 8000):
+    # 16384 / 16385: either side of the LDS-resident form; 31120 / 48000: the host's connected-mode search windows
+    # (streaming_decoder.cpp:424-431), mixed down into the device workspace
+    for buf_len in (4512, 3000, 1016, 1500, 900, 8000, 16384, 16385, 31120, 48000):
         bufs, known = [], []
-        for t in range(48):
+        for t in range(48 if buf_len <= 8000 else 10):
             root = (1, 3, 5, 7)[t % 4]
             snr_db = (-10, -5, 0, 5, 10, 25)[t % 6]
             cfo = (-23.0, -10.0, 0.0, 10.0, 23.0)[t % 5]
