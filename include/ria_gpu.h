@@ -102,7 +102,8 @@ typedef struct ria_decode_status {
     uint8_t  frame_valid;     /* 1: header+frame CRC verified on the reassembled frame */
     uint8_t  needs_recovery;  /* 1: all codewords converged but the frame CRC failed (LDPC false
                                  positive, frame_v2.cpp:1564-1880): ria_gpu_decode_* finishes it */
-    uint8_t  reserved[2];
+    uint8_t  reserved[2];     /* reserved[1] == 0xEE: an internal work queue of this call broke its bound; then every frame of the
+                                 call is reported failed (cw_ok 0, frame_valid 0, zero bytes) and the host-buffer forms return RIA_ERR_HIP */
 } ria_decode_status;
 
 /* decode flags */
@@ -133,7 +134,8 @@ int  ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out);
  *                        variables RIA_SPLIT_PARTS / RIA_NO_SPLIT may override). */
 #define RIA_OPT_SPLIT_PARTS 1
 /*   RIA_OPT_DUAL_DECODER the retry kernels (phase 0, cascade) decode two codewords per wavefront on an interleaved LDS
- *                        image (ldpc_dual.hip.h): 1 = on, -1 = off, 0 = library default (off; RIA_DUAL=1 turns it on). */
+ *                        image (ldpc_dual.hip.h): 1 = on, -1 = off, 0 = library default (off).  An experiment record that
+ *                        measured slower: only in builds made with -DRIA_WITH_DUAL_DECODER; elsewhere 1 is RIA_ERR_UNSUPPORTED. */
 #define RIA_OPT_DUAL_DECODER 2
 int  ria_gpu_set_option(ria_gpu_handle h, int option, int value);
 

@@ -22,11 +22,33 @@ def _sources():
     return out
 
 
+STAMP = LIB + ".flags"   # the compiler flags the library on disk was built with (one line)
+
+
+def flags_line():
+    return " ".join(HIPCC_FLAGS)
+
+
 def needs_build():
+    """A library is current when it is newer than every source AND was built with today's flags (a prebuilt library
+    shipped without its stamp counts as current only where there is no compiler to rebuild it: see build())."""
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    if any(os.path.getmtime(s) > t for s in _sources()):
+        return True
+    try:
+        return open(STAMP).read().strip() != flags_line()
+    except OSError:
+        return True
+
+
+def under_profiler():
+    """rocprofv3 (and friends) preload a tool library into every child: a hipcc started from here would inherit it, which
+    this pool forbids (the profiler initialises the GPU in each process it is loaded into)."""
+    env = os.environ
+    return any("rocprof" in env.get(k, "").lower() or "roctracer" in env.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")) \
+        or "ROCPROFILER_LIBRARY_PATH" in env
 
 
 def build(force=False, verbose=False):
@@ -36,6 +58,11 @@ def build(force=False, verbose=False):
     lock, into a temporary name that is renamed into place; the others wait, re-check and load the finished library."""
     if not force and not needs_build():
         return LIB
+    if under_profiler():
+        if os.path.exists(LIB) and not force:
+            raise RuntimeError("libria_gpu.so is out of date and this process runs under a profiler: build first (python -m ria_amd.build), "
+                               "then profile - the compiler must not be started from a profiled process")
+        raise RuntimeError("refusing to start hipcc from a profiled process: run python -m ria_amd.build first")
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if os.path.exists(LIB):
@@ -55,6 +82,8 @@ def build(force=False, verbose=False):
             try:
                 subprocess.check_call(cmd, cwd=CSRC)
                 os.replace(tmp, LIB)
+                with open(STAMP, "w") as f:
+                    f.write(flags_line() + "\n")
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)

@@ -463,11 +463,17 @@ struct DecodeCtl {          // zeroed by hipMemsetAsync before every decode call
     unsigned int queue_fault;  // set by a persistent wave whose queue loop ran past its bound (see kQueueGuard)
     unsigned int pad_[3];
 };
-// Every persistent work-queue loop is bounded: a wave can pop at most `total` live units plus one terminating index,
-// so a loop that has gone round more often than that is broken (in round 1 a lane-0-only form of the queue pop looped
-// on unit 0 for ever; the cause was not isolated).  The pops are written in the all-lane form (lane 0 adds 1, the
-// others 0, readfirstlane), which has no divergent branch, and a loop that still exceeds its bound records it in
-// DecodeCtl::queue_fault and leaves instead of hanging the GPU.
+// Queue pops are written in the all-lane form (lane 0 adds 1, the others 0, then readfirstlane).  The round-1 hang had this
+// cause, read off the ISA of tools/probes/queue_pop_probe.hip: with the pop written `u = 0; if (lane == 0) u = atomicAdd(..);
+// u = readfirstlane(u)` (or __shfl(u, 0)), hipcc 7.2 threads the lane != 0 edge of that branch THROUGH the convergent
+// broadcast, folding the constant 0 those lanes carry: the single loop becomes a nest in which lane 0 alone leaves the inner
+// loop to pop the queue, while lanes 1..63 re-enter the loop body with EXEC = ~lane0 and `v_mov_b32 u, 0` +
+// `v_readfirstlane` of the first ACTIVE lane - unit 0 again, for ever, since 0 < total.  The all-lane form has no
+// divergent branch in front of the broadcast, so there is nothing to thread.  Every persistent loop is bounded as well: a
+// wave can pop at most `total` live units plus one terminating index; a loop that goes round more often records it in
+// DecodeCtl::queue_fault and leaves, and the call's last kernel turns a recorded fault into "every frame failed"
+// (decode_fault_mark) - a broken queue loop is reported through the status records, it neither hangs the GPU nor returns
+// undecoded frames as if they had been tried.
 #define RIA_QUEUE_GUARD(guard, total, ctl) \
     if (++(guard) > (total) + 2u) { if (threadIdx.x == 0) atomicExch(&(ctl)->queue_fault, 1u); break; }
 
@@ -776,12 +782,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S::kCascadeW
             prev = __builtin_amdgcn_readfirstlane(prev);
             if (a < prev) {   // best so far: publish under the entry's lock (held for one 40..68-byte store)
                 CascadeWin* w = A.win + e;
-                for (unsigned spin = 0;; ++spin) {   // wave-uniform spin: lane 0's compare-and-swap decides
+                // the holder is a resident wave inside a 40..68-byte store, so the lock frees within microseconds; the spin
+                // is bounded all the same (2^20 x 64 cycles = 28 ms): past that the wave records a fault and moves on
+                bool mine = false;
+                for (unsigned spin = 0; spin < (1u << 20); ++spin) {   // wave-uniform spin: lane 0's compare-and-swap decides
                     unsigned got = atomicCAS(&w->lock, 0u, lane == 0 ? 1u : 0u);
                     got = __builtin_amdgcn_readfirstlane(got);
-                    if (got == 0u) break;
+                    if (got == 0u) { mine = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (!mine) { if (lane == 0) atomicExch(&A.ctl->queue_fault, 1u); continue; }
                 __threadfence();
                 unsigned int cur = __hip_atomic_load(&A.best[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cur = __builtin_amdgcn_readfirstlane(cur);
@@ -818,16 +828,30 @@ __global__ __launch_bounds__(256) void fast_finalize_kernel(FastDecodeArgs A) {
 // ------------------------------------------------------------------------------------------------ kernel D4
 // frame validity: parseHeader + DataFrame::deserialize on the straight concatenation
 // (frame_v2.cpp:1195-1252, :556-600); CW1..3 starting with 0xD5 go to the host restatement.
-__global__ __launch_bounds__(256) void frame_validate_kernel(const uint8_t* __restrict__ info, int bpc, int n_frames,
+// A work-queue fault recorded during this call (DecodeCtl::queue_fault, see RIA_QUEUE_GUARD): some units were never decoded,
+// so no result of the call can be trusted - every frame is reported failed, with the marker 0xEE in reserved[1].
+__device__ inline bool decode_fault_mark(const DecodeCtl* ctl, ria_decode_status* s, uint8_t* info, int info_bytes, int lane) {
+    if (__hip_atomic_load(&ctl->queue_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return false;
+    for (int b = lane; b < info_bytes; b += 64) info[b] = 0;
+    if (lane == 0) {
+        for (int cw = 0; cw < 4; ++cw) s->cw_ok[cw] = 0;
+        s->frame_valid = 0; s->needs_recovery = 0; s->reserved[0] = 0; s->reserved[1] = 0xEE;
+    }
+    return true;
+}
+constexpr uint8_t kDecodeFaultMarker = 0xEE;
+
+__global__ __launch_bounds__(256) void frame_validate_kernel(uint8_t* __restrict__ info, int bpc, int n_frames,
                                                              const uint16_t* __restrict__ crc_bit,
                                                              const uint16_t* __restrict__ crc_init,
-                                                             ria_decode_status* __restrict__ status) {
+                                                             ria_decode_status* __restrict__ status, const DecodeCtl* ctl) {
     __shared__ uint8_t flat_all[4][4 * 68];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.x * 4 + wave;
     if (frame >= n_frames) return;
     uint8_t* flat = flat_all[wave];
     ria_decode_status* s = status + frame;
+    if (decode_fault_mark(ctl, s, info + static_cast<size_t>(frame) * 4 * bpc, 4 * bpc, lane)) return;
     const bool all_ok = s->cw_ok[0] && s->cw_ok[1] && s->cw_ok[2] && s->cw_ok[3];
     int valid = 0, quirk = 0;
     if (all_ok) {
@@ -858,6 +882,14 @@ __global__ __launch_bounds__(256) void frame_validate_kernel(const uint8_t* __re
         s->reserved[0] = static_cast<uint8_t>(quirk);
         s->reserved[1] = 0;
     }
+}
+
+// last kernel of a call whose CRC recovery ran after frame_validate_kernel: the same fault check over every frame
+__global__ __launch_bounds__(256) void decode_fault_kernel(const DecodeCtl* ctl, ria_decode_status* __restrict__ status, uint8_t* __restrict__ info,
+                                                           int bpc, int n_frames) {
+    const int lane = threadIdx.x & 63, frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= n_frames) return;
+    (void)decode_fault_mark(ctl, status + frame, info + static_cast<size_t>(frame) * 4 * bpc, 4 * bpc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ raw rows

@@ -295,6 +295,15 @@ __device__ inline int rec_search(const RecCtx& x, LlrFn llr) {
                     }
                 } else if (hdr && ctl2) {
                     done = true;                              // a control frame verifies on its header alone (not reachable: the single-bit pass would have taken it)
+                } else if (!hdr) {
+                    // b1 repairs magic and header CRC, yet the frame does not parse: a control-type byte whose own CRC over
+                    // bytes 0..17 (stored in 18..19) fails.  The reference still verifies every b2 > b1 that passes the
+                    // filter (frame_v2.cpp:1617-1640), and a b2 in bytes 17..19 can complete such a control frame: take
+                    // the exhaustive walk here (bits below 136 would break the filter again; rare, so no shortcut)
+                    for (int bb = (b1 + 1 > 136) ? b1 + 1 : 136; bb < tb && !done; ++bb) {
+                        rec_flip(x, bb >> 3, bb & 7);
+                        if (rec_try(x)) done = true; else rec_flip(x, bb >> 3, bb & 7);
+                    }
                 }
                 if (done) return true;
                 rec_flip(x, b1 >> 3, b1 & 7);

@@ -22,7 +22,9 @@
 #include "frame_recovery.hpp"
 #include "ldpc_kernels.hip.h"
 #include "ldpc_fast.hip.h"
+#ifdef RIA_WITH_DUAL_DECODER   // experiment record (two codewords per wave; measured slower): not in the default library
 #include "ldpc_dual.hip.h"
+#endif
 #include "recovery_kernels.hip.h"
 #include "demod_kernels.hip.h"
 #include "tx_kernels.hip.h"
@@ -189,8 +191,10 @@ static void set_fast_attributes(int rate, int wb) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_robust_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
+#ifdef RIA_WITH_DUAL_DECODER
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_phase0_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, DualInfo<S>::lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dual_cascade_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, DualInfo<S>::lds_bytes);
+#endif
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(recovery_fill_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, wb);
     });
 }
@@ -279,7 +283,9 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
     R.n_flagged = rctl; R.n_list2 = rctl + 1; R.n_stage2 = rctl + 2; R.next_fill = rctl + 3; R.n_overflow = rctl + 4;
     R.flagged = h->d_flagged + ws_off; R.list2 = h->d_list2 + static_cast<size_t>(ws_off) * 16; R.stage2 = h->d_stage2 + ws_off;
     R.overflow = h->d_overflow + ws_off;
+#ifdef RIA_DEBUG_STAMPS   // diagnostic builds only (tools/build_variant.sh ... -DRIA_DEBUG_STAMPS): a raw device pointer from the environment
     if (const char* e = getenv("RIA_DEBUG_REC_STAMPS")) R.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     R.list_units_now = 0;
     if (hipMemsetAsync(rctl, 0, 32, s) != hipSuccess) return fail(h, RIA_ERR_HIP, "hipMemsetAsync failed");
     const int rl = recovery_lds_bytes(h->geo.bytes_per_codeword);
@@ -290,6 +296,9 @@ static int run_crc_recovery(ria_gpu_handle h, const FastDecodeArgs& D, hipStream
         hipLaunchKernelGGL(recovery_fill_kernel<S>, dim3(std::min(n_frames * 16, 3072)), dim3(64), h->wave_lds, s, R);
     });
     hipLaunchKernelGGL(recovery_stage2_kernel, dim3(n_frames), dim3(64), rl, s, R);
+    // a work-queue fault recorded anywhere in this call (cascade, phase 0, recovery fill) turns every frame into a failure
+    hipLaunchKernelGGL(decode_fault_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, s, static_cast<const DecodeCtl*>(D.ctl), D.status, D.info_out,
+                       h->geo.bytes_per_codeword, n_frames);
     if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "recovery kernel launch failed");
     return RIA_OK;
 }
@@ -545,7 +554,12 @@ int ria_gpu_get_geometry(ria_gpu_handle h, ria_gpu_geometry* out) {
 int ria_gpu_set_option(ria_gpu_handle h, int option, int value) {
     if (!h) return RIA_ERR_INVALID;
     if (option == RIA_OPT_SPLIT_PARTS && value >= 0 && value <= kMaxParts) { h->split_parts = value; return RIA_OK; }
-    if (option == RIA_OPT_DUAL_DECODER && value >= -1 && value <= 1) { h->dual_decoder = value; return RIA_OK; }
+    if (option == RIA_OPT_DUAL_DECODER && value >= -1 && value <= 1) {
+#ifndef RIA_WITH_DUAL_DECODER
+        if (value > 0) return fail(h, RIA_ERR_UNSUPPORTED, "ria_gpu_set_option: this build does not contain the two-codewords-per-wave kernels (-DRIA_WITH_DUAL_DECODER)");
+#endif
+        h->dual_decoder = value; return RIA_OK;
+    }
     return fail(h, RIA_ERR_INVALID, "ria_gpu_set_option: unknown option %d or value %d out of range", option, value);
 }
 
@@ -618,8 +632,12 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
     // RIA_OPT_DUAL_DECODER / RIA_DUAL=1: the retry kernels decode two codewords per wave (ldpc_dual.hip.h) on 2 waves per
     // SIMD instead of one codeword per wave on 3.  Same results (tested); measured slower on the bench workload
     // (DESIGN.md section 4), so it is not the default.
+#ifdef RIA_WITH_DUAL_DECODER
     static const bool dual_env = getenv("RIA_DUAL") && getenv("RIA_DUAL")[0] == '1';
     const bool dual = h->dual_decoder > 0 || (h->dual_decoder == 0 && dual_env);
+#else
+    const bool dual = false;
+#endif
     static const int grid_env = getenv("RIA_PERSIST_GRID") ? std::max(64, atoi(getenv("RIA_PERSIST_GRID"))) : 0;
     const int persist_grid = grid_env ? grid_env : (dual ? 2048 : 3072);
     static const bool dbg = getenv("RIA_DEBUG_SYNC") != nullptr;   // stage-by-stage sync + trace on stderr
@@ -640,23 +658,29 @@ static int launch_decode(ria_gpu_handle h, const float* llr_dev, int llr_stride,
             stage("stage");
         }
         if (flags & (RIA_DECODE_PHASE0 | RIA_DECODE_PERTURB)) {
+#ifdef RIA_WITH_DUAL_DECODER
             if (dual) hipLaunchKernelGGL(dual_phase0_kernel<S>, dim3(std::min(n_frames * 8, persist_grid)), dim3(64), DualInfo<S>::lds_bytes, s, A);
-            else hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, persist_grid)), dim3(64), wb, s, A);
+            else
+#endif
+            hipLaunchKernelGGL(fast_phase0_kernel<S>, dim3(std::min(n_frames * 16, persist_grid)), dim3(64), wb, s, A);
         }
         stage("phase0");
         hipLaunchKernelGGL(fast_chain_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, A);
         stage("chain");
         if (flags & RIA_DECODE_PERTURB) {
             // persistent waves over the device-side work list; sized to fill the chip (256 CUs x 12)
+#ifdef RIA_WITH_DUAL_DECODER
             if (dual) hipLaunchKernelGGL(dual_cascade_kernel<S>, dim3(persist_grid), dim3(64), DualInfo<S>::lds_bytes, s, A);
-            else hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(persist_grid), dim3(64), wb, s, A);
+            else
+#endif
+            hipLaunchKernelGGL(fast_cascade_kernel<S>, dim3(persist_grid), dim3(64), wb, s, A);
             stage("cascade");
             hipLaunchKernelGGL(fast_finalize_kernel, dim3(std::min((4 * n_frames + 255) / 256, 1024)), dim3(256), 0, s, A);
             stage("finalize");
         }
     });
     hipLaunchKernelGGL(frame_validate_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, s, info_out_dev,
-                       h->geo.bytes_per_codeword, n_frames, A.crc_bit, A.crc_init, status_dev);
+                       h->geo.bytes_per_codeword, n_frames, A.crc_bit, A.crc_init, status_dev, static_cast<const DecodeCtl*>(A.ctl));
     stage("validate");
     if (hipGetLastError() != hipSuccess) return fail(h, RIA_ERR_HIP, "decode kernel launch failed");
     if (flags & RIA_DECODE_CRC_RECOVER) return run_crc_recovery(h, A, s, slot, ws_off);
@@ -692,7 +716,9 @@ int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64
     A.llr_stride = h->geo.llrs_per_frame;
     A.status = status_dev;
     A.dbg = nullptr;
+#ifdef RIA_DEBUG_STAMPS
     if (const char* e = getenv("RIA_DEBUG_DEMOD_STAMPS")) A.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     launch_demod(A, h->geo, static_cast<hipStream_t>(stream));
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
@@ -818,7 +844,10 @@ int ria_gpu_rx_frames_host(ria_gpu_handle h, const float* samples_host, const ri
     HIP_TRY(h, hipMemcpyAsync(P + out0, D + out0, total - out0, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     if (llr_out_host) std::memcpy(llr_out_host, P + o_llr, b_llr);
-    if (!demod_only) { std::memcpy(info_out_host, P + o_info, b_info); std::memcpy(decode_status_host, P + o_ds, b_ds); }
+    if (!demod_only) {
+        std::memcpy(info_out_host, P + o_info, b_info); std::memcpy(decode_status_host, P + o_ds, b_ds);
+        if (decode_status_host[0].reserved[1] == kDecodeFaultMarker) return fail(h, RIA_ERR_HIP, "decode work-queue fault: no frame of this call was decoded");
+    }
     if (demod_status_host) std::memcpy(demod_status_host, P + o_fs, b_fs);
     return RIA_OK;
 }
@@ -844,6 +873,7 @@ int ria_gpu_decode_frames_host(ria_gpu_handle h, const float* llr_host, int llr_
     HIP_TRY(h, hipStreamSynchronize(s));
     std::memcpy(info_out_host, P + o_info, b_info);
     std::memcpy(status_host, P + o_ds, b_ds);
+    if (status_host[0].reserved[1] == kDecodeFaultMarker) return fail(h, RIA_ERR_HIP, "decode work-queue fault: no frame of this call was decoded");
     return RIA_OK;
 }
 

@@ -1,5 +1,6 @@
-"""Identity of the kernel sources a measurement belongs to: sha256 over ria_amd/csrc/* (names and contents, sorted).
-bench.py only quotes PMC-derived figures from a profiles/ file whose recorded hash equals the current one."""
+"""Identity of the kernel build a measurement belongs to: sha256 over ria_amd/csrc/* (names and contents, sorted) and the
+compiler flags of ria_amd/build.py.  bench.py only quotes PMC-derived figures from a profiles/ file whose recorded hash equals
+the current one."""
 import hashlib
 import os
 
@@ -15,4 +16,6 @@ def csrc_sha256():
             with open(p, "rb") as f:
                 h.update(f.read())
             h.update(b"\0")
+    from .build import flags_line
+    h.update(b"flags\0" + flags_line().encode())
     return h.hexdigest()

@@ -45,7 +45,14 @@ def test_rx_batch_split_modes_are_bit_identical_and_match_the_reference(oracle):
             torch.cuda.synchronize()
             runs.setdefault(parts, []).append((out.cpu().numpy().copy(), e.decode_status(st).copy()))
     # the two-codewords-per-wave retry kernels (ldpc_dual.hip.h) on the same batch, one stream and the default split
-    for parts in (1, 0):
+    # (an experiment record: only in libraries built with -DRIA_WITH_DUAL_DECODER; the default build refuses the option)
+    from ria_amd import capi
+    try:
+        e.set_dual_decoder(1)
+        has_dual = True
+    except capi.RiaError:
+        has_dual = False
+    for parts in (1, 0) if has_dual else ():
         e.set_split_parts(parts)
         e.set_dual_decoder(1)
         out, st = e.rx(x)
