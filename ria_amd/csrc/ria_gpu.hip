@@ -61,6 +61,7 @@ struct ria_gpu {
     // Schmidl-Cox acquisition: LTS passband templates (built at first use) and the metric-table workspace
     void* d_cox_tI = nullptr; void* d_cox_tQ = nullptr; float cox_energy_ref = 0.0f; void* d_cox_ws = nullptr; size_t cox_ws_floats = 0;
     void* d_demod_const = nullptr;
+    void* d_demod_ws[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // split demodulator: bins / CFO / phase markers of one chunk, per stream slot
     void* d_tx_const = nullptr;
     // workspace
     float* d_llr_ws = nullptr;            // max_batch * llrs_per_frame (fused path)
@@ -419,6 +420,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
     for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws, h->d_txcfo_ws, h->d_zc_ws}) if (p) (void)hipFree(p);
+    for (void* p : h->d_demod_ws) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c, (void*)h->d_overflow}) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->p_rctl, (void*)h->p_flagged, (void*)h->p_info_c, (void*)h->p_rows_c, (void*)h->p_redec_ok,
@@ -697,13 +699,8 @@ int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride,
 }
 
 // ------------------------------------------------------------------------------------------------ demod
-int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
-                        const ria_frame_meta* meta_dev, int n_frames, float* llr_out_dev,
-                        ria_frame_status* status_dev, void* stream) {
-    if (h && n_frames == 0) return RIA_OK;
-    if (!h || !samples_dev || !llr_out_dev || n_frames < 0)
-        return fail(h, RIA_ERR_INVALID, "ria_gpu_demod_batch: bad argument");
-    HIP_TRY(h, hipSetDevice(h->device));
+static int demod_batch_slot(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev, const ria_frame_meta* meta_dev,
+                            int n_frames, float* llr_out_dev, ria_frame_status* status_dev, hipStream_t stream, int slot) {
     DemodArgs A;
     A.k = static_cast<const DemodConst*>(h->d_demod_const);
     A.twiddle = static_cast<const float2*>(h->d_twiddle);
@@ -719,9 +716,24 @@ int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64
 #ifdef RIA_DEBUG_STAMPS
     if (const char* e = getenv("RIA_DEBUG_DEMOD_STAMPS")) A.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
-    launch_demod(A, h->geo, static_cast<hipStream_t>(stream));
+    static const bool fused = getenv("RIA_DEMOD_FUSED") && getenv("RIA_DEMOD_FUSED")[0] == '1';
+    if (fused) launch_demod_fused(A, stream);
+    else {
+        if (!h->d_demod_ws[slot]) HIP_TRY(h, hipMalloc(&h->d_demod_ws[slot], demod_ws_bytes(2 + h->geo.n_data_symbols)));
+        launch_demod(A, h->geo, h->cfg.modulation, h->d_demod_ws[slot], stream);
+    }
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
+}
+
+int ria_gpu_demod_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
+                        const ria_frame_meta* meta_dev, int n_frames, float* llr_out_dev,
+                        ria_frame_status* status_dev, void* stream) {
+    if (h && n_frames == 0) return RIA_OK;
+    if (!h || !samples_dev || !llr_out_dev || n_frames < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_demod_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return demod_batch_slot(h, samples_dev, frame_offsets_dev, meta_dev, n_frames, llr_out_dev, status_dev, static_cast<hipStream_t>(stream), 0);
 }
 
 int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t* frame_offsets_dev,
@@ -772,8 +784,8 @@ int ria_gpu_rx_batch(ria_gpu_handle h, const float* samples_dev, const uint64_t*
             const uint64_t* offs = frame_offsets_dev ? frame_offsets_dev + g0 : nullptr;
             const float* smp = frame_offsets_dev ? samples_dev : samples_dev + static_cast<size_t>(g0) * h->geo.frame_samples;
             float* pl = llr + static_cast<size_t>(p0) * h->geo.llrs_per_frame;
-            int rc = ria_gpu_demod_batch(h, smp, offs, meta_dev ? meta_dev + g0 : nullptr, pn, pl,
-                                         demod_status_dev ? demod_status_dev + g0 : nullptr, ps);
+            int rc = demod_batch_slot(h, smp, offs, meta_dev ? meta_dev + g0 : nullptr, pn, pl,
+                                      demod_status_dev ? demod_status_dev + g0 : nullptr, ps, part);
             if (rc != RIA_OK) return rc;
             rc = launch_decode(h, pl, h->geo.llrs_per_frame, pn, flags, info_out_dev + static_cast<size_t>(g0) * h->geo.info_bytes_per_frame,
                                decode_status_dev + g0, ps, part, p0);
