@@ -264,7 +264,7 @@ def test_robust_single_cw_decode_vs_reference_golden(golden):
     """ria_gpu_ldpc_decode_robust_batch = robustDecodeSingleCW (streaming_decoder.cpp:1028-1058): success, number of
     decodes, iteration count of the last one and its bytes, against vectors recorded from the reference."""
     g = golden("robust_ldpc")
-    for rate, rn in ((po.R1_4, "R1_4"), (po.R1_2, "R1_2"), (po.R3_4, "R3_4")):
+    for rate, rn in ((po.R1_4, "R1_4"), (po.R1_2, "R1_2"), (po.R3_4, "R3_4"), (po.R1_3, "R1_3"), (po.R2_3, "R2_3"), (po.R5_6, "R5_6")):
         e = engine("QAM16", rn)
         r = g[f"res_{rate}"]
         out, ok, it, tries = e.ldpc_decode_robust(dev(g[f"llr_{rate}"]))

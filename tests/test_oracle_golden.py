@@ -297,7 +297,7 @@ def test_burst_interleaver_oracle_matches_reference_golden(oracle, golden):
 def test_robust_single_cw_oracle_matches_reference_golden(oracle, golden):
     """robustDecodeSingleCW (streaming_decoder.cpp:1028-1058): five-factor decoder diversity, recorded from the reference."""
     g = golden("robust_ldpc")
-    for rate in (po.R1_4, po.R1_2, po.R3_4):
+    for rate in (po.R1_4, po.R1_2, po.R3_4, po.R1_3, po.R2_3, po.R5_6):
         for llr, r in zip(g[f"llr_{rate}"], g[f"res_{rate}"]):
             ok, out, it, tries = oracle.robust_decode(rate, llr)
             assert (int(ok), tries, it) == (int(r[0]), int(r[1]), int(r[2])), (rate, r[:3], ok, tries, it)
