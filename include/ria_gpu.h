@@ -337,6 +337,10 @@ int ria_gpu_ldpc_decode_robust_host(ria_gpu_handle h, const float* llr_host, int
  * buffer (multi_carrier_dpsk.hpp:141-281); returns the sample count or -needed.  Bit-identical audio. */
 int ria_gpu_mcdpsk_modulate_host(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data, int n_bytes,
                                  float* out_host, int max_n);
+/* The same modulator for a batch on the device: data_dev = n_frames rows of n_bytes coded bytes, frame f written to
+ * out_dev + f*out_stride ((9 + ceil(8 n_bytes / (carriers * bits)) * spreading) * 512 samples).  Bit-identical audio. */
+int ria_gpu_mcdpsk_modulate_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data_dev, int n_bytes, int n_frames,
+                                  float* out_dev, int64_t out_stride, void* stream);
 /* fec::ChaseCache::store arithmetic for n_cw codeword slots of 648 LLRs (chase_cache.cpp:27-88): count 0 ->
  * copy, else add; skipped when decoded_dev[cw] != 0 or count >= 4.  stored_out_dev (nullable) gets 1/0. */
 int ria_gpu_chase_combine_batch(ria_gpu_handle h, float* acc_dev, int32_t* count_dev, const uint8_t* decoded_dev,

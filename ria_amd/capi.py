@@ -22,7 +22,7 @@ EXPORTS = [
     "ria_gpu_channel_batch", "ria_gpu_channel_exact_batch", "ria_gpu_channel_exact_seeded_batch", "ria_gpu_debug_math", "ria_gpu_debug_queue_fault", "ria_gpu_sync_zc_batch", "ria_gpu_zc_preamble", "ria_gpu_sync_chirp_batch", "ria_gpu_chirp_preamble", "ria_gpu_mcdpsk_demod_batch",
     "ria_gpu_mcdpsk_modulate_host", "ria_gpu_chase_combine_batch", "ria_gpu_sync_lts_batch", "ria_gpu_sync_host", "ria_gpu_ldpc_encode_host", "ria_gpu_burst_deinterleave_batch", "ria_gpu_burst_interleave_batch",
     "ria_gpu_sync_cox_batch", "ria_gpu_cox_preamble", "ria_gpu_channel_exact_cfo_batch", "ria_gpu_tx_cfo_batch",
-    "ria_gpu_mcdpsk_demod_host", "ria_gpu_ldpc_decode_robust_host",
+    "ria_gpu_mcdpsk_demod_host", "ria_gpu_ldpc_decode_robust_host", "ria_gpu_mcdpsk_modulate_batch",
     "ria_link_recommend", "ria_link_data_mode", "ria_link_ofdm_code_rate", "ria_link_cap_initial_rate",
 ]
 
@@ -111,6 +111,7 @@ def load(build_if_needed=True):
     L.ria_gpu_channel_exact_batch.argtypes = [vp, i32, f32, u32, u64, vp, C.c_int64, i32, i32, vp]
     L.ria_gpu_channel_exact_seeded_batch.argtypes = [vp, i32, f32, vp, vp, C.c_int64, i32, i32, vp]
     L.ria_gpu_channel_exact_cfo_batch.argtypes = [vp, i32, f32, vp, vp, f32, vp, vp, C.c_int64, i32, i32, vp]
+    L.ria_gpu_mcdpsk_modulate_batch.argtypes = [vp, vp, vp, i32, i32, vp, C.c_int64, vp]
     L.ria_gpu_mcdpsk_demod_host.argtypes = [vp, vp, vp, i32, f32, f32, vp, i32, vp]
     L.ria_gpu_ldpc_decode_robust_host.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.ria_gpu_tx_cfo_batch.argtypes = [vp, vp, C.c_int64, i32, i32, vp, vp, vp, C.c_int64, vp]

@@ -837,6 +837,25 @@ inline std::vector<float> build_hilbert(int taps) {   // HilbertTransform ctor, 
     }
     return c;
 }
+// tables of the device modulator: carrier[c][i] = (cos, sin)(i * phase_inc_c), train[sym][c] = (cos, sin)(c * sym * pi / 2)
+inline void build_mcdpsk_mod_tables(int nc, std::vector<float>& carrier, std::vector<float>& train) {
+    const std::vector<float> fr = mcdpsk_freqs(nc);
+    carrier.assign(static_cast<size_t>(nc) * kMcdSps * 2, 0.0f);
+    train.assign(static_cast<size_t>(kMcdTrain) * nc * 2, 0.0f);
+    for (int c = 0; c < nc; ++c) {
+        const float inc = mcdpsk_phase_inc(fr[c]);
+        for (int i = 0; i < kMcdSps; ++i) {
+            const float t = i * inc;
+            carrier[(static_cast<size_t>(c) * kMcdSps + i) * 2] = 1.0f * cosf_glibc(t);
+            carrier[(static_cast<size_t>(c) * kMcdSps + i) * 2 + 1] = 1.0f * sinf_glibc(t);
+        }
+        for (int sym = 0; sym < kMcdTrain; ++sym) {
+            const float po = static_cast<float>(static_cast<double>(c * sym) * 3.14159265358979323846 / static_cast<double>(2.0f));
+            train[(static_cast<size_t>(sym) * nc + c) * 2] = 1.0f * cosf_glibc(po);
+            train[(static_cast<size_t>(sym) * nc + c) * 2 + 1] = 1.0f * sinf_glibc(po);
+        }
+    }
+}
 // training + reference + data audio (:141-281)
 inline std::vector<float> build_mcdpsk_frame(int nc, int bps, int spreading, const uint8_t* data, int n_bytes) {
     const std::vector<float> fr = mcdpsk_freqs(nc);

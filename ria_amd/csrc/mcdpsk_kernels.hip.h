@@ -280,6 +280,73 @@ __host__ __device__ inline int mcdpsk_lds_bytes(int nc, int frame_samples, int s
     return nc * kMcSps * 8 + (3 + num_rx) * nc * 8 + 3 * nds * nc * 4 + (kMcMaxCarriers + 8) * 4 + 64;
 }
 
+// MultiCarrierDPSKModulator on the device (multi_carrier_dpsk.hpp:141-281): training (8 symbols) + reference + data audio
+// of a batch of frames, bit-identical to the host builder (host_tables.hpp build_mcdpsk_frame).  One workgroup per frame:
+//   * the differential chain prev <- normalise(prev * phase(bits)) is serial over the data symbols but independent per
+//     carrier: lane c walks carrier c and parks the transmitted symbols in LDS;
+//   * a sample is the left-to-right sum over the carriers of real(symbol * carrier_table[c][i]) / nc: one lane per sample;
+//   * the carrier table (cos, sin)(i * phase_inc_c) and the training rotations are per-handle tables built once on the
+//     host with the bit-exact libm restatement (the same values for every frame).
+struct McModArgs {
+    const uint8_t* data; int n_bytes; int n_frames;   // [n_frames][n_bytes] coded bytes (MSB first)
+    int nc, bps, spreading, n_data_sym;
+    const float2* carrier;    // [nc][512]  (cos, sin)(i * phase_inc_c)
+    const float2* train;      // [8][nc]    (cos, sin)(c * sym * pi / 2)
+    float* out; long long stride;
+};
+__global__ __launch_bounds__(256) void mcdpsk_modulate_kernel(McModArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* symb = reinterpret_cast<float2*>(smem);                        // [n_data_sym][nc]
+    const int tid = threadIdx.x, f = blockIdx.x, nc = A.nc, bps = A.bps;
+    const uint8_t* data = A.data + static_cast<size_t>(f) * A.n_bytes;
+    const int n_bits = A.n_bytes * 8;
+    if (tid < nc) {
+        float pr = 1.0f, pi = 0.0f;                                        // the reference symbol is +1 on every carrier
+        for (int ds = 0; ds < A.n_data_sym; ++ds) {
+            int sb = 0;
+            for (int b = 0; b < bps; ++b) {
+                const int bit_idx = (ds * nc + tid) * bps + b;
+                const int bit = (bit_idx < n_bits) ? (data[bit_idx >> 3] >> (7 - (bit_idx & 7))) & 1 : 0;
+                sb = (sb << 1) | bit;
+            }
+            float pc;
+            if (bps == 2) {
+                const double kPi = 3.14159265358979323846;
+                pc = (sb == 0) ? static_cast<float>(kPi / 4) : (sb == 1) ? static_cast<float>(3 * kPi / 4) : (sb == 2) ? static_cast<float>(-3 * kPi / 4) : static_cast<float>(-kPi / 4);
+            } else {
+                pc = sb ? static_cast<float>(3.14159265358979323846) : 0.0f;
+            }
+            const float dr = 1.0f * cosf_glibc(pc), di = 1.0f * sinf_glibc(pc);
+            float cr = pr * dr - pi * di, ci = pr * di + pi * dr;
+            const float a = hypotf_glibc(cr, ci);
+            cr = fdiv(cr, a); ci = fdiv(ci, a);
+            pr = cr; pi = ci;
+            symb[ds * nc + tid] = make_float2(cr, ci);
+        }
+    }
+    __syncthreads();
+    float* out = A.out + static_cast<long long>(f) * A.stride;
+    const float ncf = static_cast<float>(nc);
+    const int n_unique = kMcTrain + 1 + A.n_data_sym;                      // symbols before spreading
+    for (int idx = tid; idx < n_unique * kMcSps; idx += 256) {
+        const int sym = idx / kMcSps, i = idx - sym * kMcSps;
+        float acc = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            float2 sv;
+            if (sym < kMcTrain) sv = A.train[sym * nc + c];
+            else if (sym == kMcTrain) sv = make_float2(1.0f, 0.0f);
+            else sv = symb[(sym - kMcTrain - 1) * nc + c];
+            const float2 cw = A.carrier[c * kMcSps + i];
+            acc += fdiv(sv.x * cw.x - sv.y * cw.y, ncf);
+        }
+        if (sym <= kMcTrain) out[idx] = acc;
+        else {
+            const int ds = sym - kMcTrain - 1;
+            for (int rep = 0; rep < A.spreading; ++rep) out[static_cast<size_t>(kMcTrain + 1 + ds * A.spreading + rep) * kMcSps + i] = acc;
+        }
+    }
+}
+
 // fec::ChaseCache::store for a batch of codeword slots (src/fec/chase_cache.cpp:27-88): first reception
 // copies, later ones add (LLR sum), at most 4 combines, decoded slots are left alone
 __global__ __launch_bounds__(256) void chase_combine_kernel(float* __restrict__ acc, int32_t* __restrict__ count,

@@ -56,6 +56,7 @@ struct ria_gpu {
     void* d_txcfo_ws = nullptr; size_t txcfo_ws_bytes = 0;
     void* d_zc_ws = nullptr; size_t zc_ws_bytes = 0;   // baseband workspace of the long-buffer ZC search
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
+    std::map<int, void*> d_mc_carrier, d_mc_train;   // device modulator tables per carrier count
     std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
     void* d_twiddle = nullptr; void* d_nco = nullptr;
     // Schmidl-Cox acquisition: LTS passband templates (built at first use) and the metric-table workspace
@@ -415,6 +416,8 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->p_hstage) (void)hipHostFree(h->p_hstage);
     for (auto& ev_ : h->aux_event) if (ev_) (void)hipEventDestroy(ev_);
     for (auto& kv : h->d_mc_mixer) if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : h->d_mc_carrier) if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : h->d_mc_train) if (kv.second) (void)hipFree(kv.second);
     if (h->d_mc_hilbert) (void)hipFree(h->d_mc_hilbert);
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
@@ -1416,6 +1419,36 @@ int ria_gpu_ldpc_decode_robust_host(ria_gpu_handle h, const float* llr_host, int
     std::memcpy(ok_host, P + o_ok, n);
     if (iters_host) std::memcpy(iters_host, P + o_it, 2 * n);
     if (tries_host) std::memcpy(tries_host, P + o_tr, n);
+    return RIA_OK;
+}
+
+int ria_gpu_mcdpsk_modulate_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, const uint8_t* data_dev, int n_bytes, int n_frames,
+                                  float* out_dev, int64_t out_stride, void* stream) {
+    if (!h) return RIA_ERR_INVALID;
+    if (n_frames == 0) return RIA_OK;
+    if (!mcdpsk_config_ok(cfg) || !data_dev || !out_dev || n_bytes < 0 || n_frames < 0)
+        return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_modulate_batch: bad arguments");
+    const int nc = cfg->num_carriers, bits_per_sym = nc * cfg->bits_per_symbol;
+    const int n_data_sym = (n_bytes * 8 + bits_per_sym - 1) / bits_per_sym;
+    const int64_t frame_samples = static_cast<int64_t>(kMcTrain + 1 + n_data_sym * cfg->spreading) * kMcSps;
+    if (out_stride < frame_samples) return fail(h, RIA_ERR_INVALID, "ria_gpu_mcdpsk_modulate_batch: out_stride too small (%lld samples per frame)", static_cast<long long>(frame_samples));
+    const int lds = n_data_sym * nc * static_cast<int>(sizeof(float2)) + 16;
+    if (lds > 64 * 1024) return fail(h, RIA_ERR_UNSUPPORTED, "ria_gpu_mcdpsk_modulate_batch: too many data symbols for one workgroup");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->d_mc_carrier.count(nc)) {
+        std::vector<float> car, tr;
+        build_mcdpsk_mod_tables(nc, car, tr);
+        void *pc = nullptr, *pt = nullptr;
+        HIP_TRY(h, upload(&pc, car));
+        HIP_TRY(h, upload(&pt, tr));
+        h->d_mc_carrier[nc] = pc; h->d_mc_train[nc] = pt;
+    }
+    McModArgs A{};
+    A.data = data_dev; A.n_bytes = n_bytes; A.n_frames = n_frames; A.nc = nc; A.bps = cfg->bits_per_symbol; A.spreading = cfg->spreading;
+    A.n_data_sym = n_data_sym; A.carrier = static_cast<const float2*>(h->d_mc_carrier[nc]); A.train = static_cast<const float2*>(h->d_mc_train[nc]);
+    A.out = out_dev; A.stride = out_stride;
+    hipLaunchKernelGGL(mcdpsk_modulate_kernel, dim3(n_frames), dim3(256), lds, static_cast<hipStream_t>(stream), A);
+    HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }
 

@@ -286,6 +286,19 @@ class RxEngine:
             raise capi.RiaError("mcdpsk_modulate failed")
         return out[:n].copy()
 
+    def mcdpsk_modulate_batch(self, data, carriers=10, bits_per_symbol=1, spreading=1):
+        """MultiCarrierDPSKModulator on the device: data uint8 [n, n_bytes] (device tensor or host array) -> float32 [n, samples]"""
+        if not torch.is_tensor(data):
+            data = torch.from_numpy(np.ascontiguousarray(data, np.uint8)).to(self.device)
+        assert data.dtype == torch.uint8 and data.is_contiguous() and data.dim() == 2
+        n, nb = data.shape
+        bits = carriers * bits_per_symbol
+        fs = (9 + ((nb * 8 + bits - 1) // bits) * spreading) * 512
+        out = torch.empty((n, fs), dtype=torch.float32, device=self.device)
+        cfg = capi.McdpskConfig(carriers, bits_per_symbol, spreading, 0)
+        self._check(self.lib.ria_gpu_mcdpsk_modulate_batch(self.h, C.byref(cfg), _ptr(data), nb, n, _ptr(out), fs, _stream_ptr()))
+        return out
+
     def chase_combine(self, acc, count, soft, decoded=None):
         """ChaseCache::store arithmetic in place on acc [n,648] / count [n] (int32); returns stored flags."""
         n = acc.shape[0]

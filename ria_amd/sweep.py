@@ -135,7 +135,7 @@ def run_harq_trials(e, carriers, bps, spreading, kind, snr_db, info21, seeds, wa
     n, max_tx = seeds.shape
     uniq, inv = np.unique(info21, axis=0, return_inverse=True)
     coded = e.ldpc_encode(uniq)
-    frames = torch.from_numpy(np.stack([e.mcdpsk_modulate(coded[i], carriers, bps, spreading) for i in range(len(uniq))])).to(dev)
+    frames = e.mcdpsk_modulate_batch(coded, carriers, bps, spreading)     # the few distinct messages, modulated on the device
     clean = frames[torch.from_numpy(np.asarray(inv).reshape(-1)).to(dev)]
     acc = torch.zeros((n, 648), dtype=torch.float32, device=dev)
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -206,7 +206,7 @@ def measured_fading_index(engines, point, base_seed, point_index, n_probe=48):
     seeds = trial_seed32(base_seed, point_index, 254, probe)[:, None]
     uniq, inv = np.unique(info, axis=0, return_inverse=True)
     coded = e.ldpc_encode(uniq)
-    frames = torch.from_numpy(np.stack([e.mcdpsk_modulate(coded[i], 10, 1, 1) for i in range(len(uniq))])).to(e.device)
+    frames = e.mcdpsk_modulate_batch(coded, 10, 1, 1)
     x = frames[torch.from_numpy(np.asarray(inv).reshape(-1)).to(e.device)].contiguous()
     e.channel_exact_seeded_(x, point.channel, point.snr_db, seeds[:, 0])
     _, st = e.mcdpsk_demod(x, 10, 1, 1)
