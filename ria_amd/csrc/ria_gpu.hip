@@ -52,6 +52,7 @@ struct ria_gpu {
     void* d_ch_tw = nullptr; void* d_ch_tmpl = nullptr; void* d_ch_tmpl_fft = nullptr; float ch_energy[2] = {0, 0};
     void* d_ch_w1 = nullptr; void* d_ch_w2 = nullptr; void* d_ch_mag = nullptr; void* d_ch_cum = nullptr; void* d_ch_st = nullptr;
     int ch_chunk = 0, ch_outer = 0;
+    hipStream_t ch_side = nullptr; hipEvent_t ch_ev[2] = {nullptr, nullptr};   // the time-domain fallback runs beside the FFT path
     // transmitter-CFO impairment (cfo_kernels.hip.h): two complex arrays + the phase table, grown on demand
     void* d_txcfo_ws = nullptr; size_t txcfo_ws_bytes = 0;
     void* d_zc_ws = nullptr; size_t zc_ws_bytes = 0;   // baseband workspace of the long-buffer ZC search
@@ -412,6 +413,8 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& st_ : h->aux_stream) if (st_) (void)hipStreamDestroy(st_);
     if (h->hstream) (void)hipStreamDestroy(h->hstream);
+    if (h->ch_side) (void)hipStreamDestroy(h->ch_side);
+    for (auto& ev_ : h->ch_ev) if (ev_) (void)hipEventDestroy(ev_);
     if (h->d_hstage) (void)hipFree(h->d_hstage);
     if (h->p_hstage) (void)hipHostFree(h->p_hstage);
     for (auto& ev_ : h->aux_event) if (ev_) (void)hipEventDestroy(ev_);
@@ -1115,6 +1118,10 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
     const int chunk = std::min(n_buffers, 64), outer = std::min(n_buffers, 2048);
     int rc = chirp_prepare(h, chunk, outer, s);
     if (rc != RIA_OK) return rc;
+    if (!h->ch_side) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->ch_side, hipStreamNonBlocking));
+        for (auto& ev_ : h->ch_ev) HIP_TRY(h, hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+    }
     ChirpArgs A{};
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.threshold = threshold;
     A.tw = static_cast<const float2*>(h->d_ch_tw); A.tmpl_fft = static_cast<const float2*>(h->d_ch_tmpl_fft);
@@ -1127,14 +1134,22 @@ int ria_gpu_sync_chirp_batch(ria_gpu_handle h, const float* samples_dev, int64_t
         for (int down = 0; down < 2; ++down) {
             A.down = down; A.sub = 0; A.n_sub = nb;
             hipLaunchKernelGGL(chirp_window_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
-            hipLaunchKernelGGL(chirp_cumsum_kernel, dim3(nb), dim3(64), 0, s, A);
-            if (down) hipLaunchKernelGGL(chirp_td_kernel, dim3(nb), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(chirp_cumsum_kernel, dim3((nb + kCumB - 1) / kCumB), dim3(64), 0, s, A);
+            if (down) {
+                // the time-domain fallback (short down windows: a few buffers, 24 000-term sums per candidate, one workgroup
+                // per buffer) touches other buffers than the FFT path and is latency-bound: it runs beside it on a side stream
+                HIP_TRY(h, hipEventRecord(h->ch_ev[0], s));
+                HIP_TRY(h, hipStreamWaitEvent(h->ch_side, h->ch_ev[0], 0));
+                hipLaunchKernelGGL(chirp_td_kernel, dim3(nb), dim3(256), 0, h->ch_side, A);
+                HIP_TRY(h, hipEventRecord(h->ch_ev[1], h->ch_side));
+            }
             for (int sub = 0; sub < nb; sub += chunk) {
                 A.sub = sub; A.n_sub = std::min(chunk, nb - sub);
                 chirp_fft_forward(A, A.n_sub, s, true, true);
                 chirp_fft_inverse_mag(A, A.n_sub, s);
                 hipLaunchKernelGGL(chirp_peak_kernel, dim3((A.n_sub + 63) / 64), dim3(64), 0, s, A);
             }
+            if (down) HIP_TRY(h, hipStreamWaitEvent(s, h->ch_ev[1], 0));
         }
         A.sub = 0; A.n_sub = nb;
         hipLaunchKernelGGL(chirp_finish_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, A);
@@ -1222,7 +1237,7 @@ int ria_gpu_sync_lts_batch(ria_gpu_handle h, const float* samples_dev, int64_t s
     LtsArgs A{};
     A.samples = samples_dev; A.stride = stride; A.buf_len = buf_len; A.n_buffers = n_buffers; A.known_cfo = known_cfo_dev;
     A.threshold = threshold; A.hilbert = static_cast<const float*>(h->d_hilbert65); A.out = out_dev;
-    hipLaunchKernelGGL(lts_sync_kernel, dim3(n_buffers), dim3(256), lts_lds_bytes(), static_cast<hipStream_t>(stream), A);
+    hipLaunchKernelGGL(lts_sync_kernel, dim3(n_buffers), dim3(kLtsThreads), lts_lds_bytes(), static_cast<hipStream_t>(stream), A);
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }

@@ -301,38 +301,61 @@ __global__ void chirp_window_kernel(ChirpArgs A) {
 }
 
 // cumsum_energy[i+1] = cumsum_energy[i] + s[i]^2 (chirp_sync.hpp:668-672).  The running float sum is serial by
-// definition; one wavefront per buffer: all lanes load a tile and square it (coalesced), lane 0 walks the
-// tile through LDS (the dependent adds are the whole cost), all lanes store the tile (coalesced).
+// definition (no re-association), and a serial chain occupies one LANE: a wavefront therefore carries kCumB buffers at once -
+// all lanes load and square a 256-sample tile of each (coalesced), lanes 0..kCumB-1 each walk their own buffer's tile through
+// LDS with ONE instruction stream (the dependent adds are the whole cost, and an instruction issued for one lane costs the
+// same as for eight), all lanes store the tiles (coalesced).  Rows are kCumRow floats apart so that the walkers' 16-byte
+// reads fall on different banks.
+constexpr int kCumB = 8, kCumRow = 256 + 8;
 __global__ __launch_bounds__(64) void chirp_cumsum_kernel(ChirpArgs A) {
-    __shared__ __attribute__((aligned(16))) float sq[256];
-    __shared__ __attribute__((aligned(16))) float cs[256];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const ChirpBufState s = A.st[b];
-    if (s.active != 1) return;
-    const float* x = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
-    float* cum = A.cum + static_cast<size_t>(b) * (kChFft + 1);
-    const int fft_in = s.win_len < kChFft ? s.win_len : kChFft;
-    float c = 0.0f;
-    if (lane == 0) cum[0] = 0.0f;
-    float nx[4];   // next tile, loaded one iteration ahead so that the HBM latency hides behind the serial walk
+    __shared__ __attribute__((aligned(16))) float sq[kCumB * kCumRow];
+    __shared__ __attribute__((aligned(16))) float cs[kCumB * kCumRow];
+    const int lane = threadIdx.x, b0 = blockIdx.x * kCumB;
+    int fft_in[kCumB], len_max = 0;
+    const float* x[kCumB];
+    float* cum[kCumB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int i = 64 * q + lane; nx[q] = (i < fft_in) ? x[i] : 0.0f; }
-    for (int base = 0; base < fft_in; base += 256) {
-        float cur[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = nx[q];
-        if (base + 256 < fft_in) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int i = base + 256 + 64 * q + lane; nx[q] = (i < fft_in) ? x[i] : 0.0f; }
+    for (int q = 0; q < kCumB; ++q) {
+        const int b = b0 + q;
+        fft_in[q] = 0; x[q] = nullptr; cum[q] = nullptr;
+        if (b < A.n_buffers) {
+            const ChirpBufState s = A.st[b];
+            if (s.active == 1) {
+                fft_in[q] = s.win_len < kChFft ? s.win_len : kChFft;
+                x[q] = A.samples + static_cast<long long>(A.first + b) * A.stride + s.win_start;
+                cum[q] = A.cum + static_cast<size_t>(b) * (kChFft + 1);
+                if (lane == 0) cum[q][0] = 0.0f;
+            }
         }
+        len_max = fft_in[q] > len_max ? fft_in[q] : len_max;
+    }
+    if (len_max == 0) return;
+    float c = 0.0f;                                           // lane q < kCumB: running sum of buffer b0 + q
+    int walk_len = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sq[64 * q + lane] = cur[q] * cur[q];
+    for (int q = 0; q < kCumB; ++q) if (lane == q) walk_len = fft_in[q];
+    float nx[kCumB][4];   // next tile of every buffer, loaded one iteration ahead so that the HBM latency hides behind the serial walk
+#pragma unroll
+    for (int q = 0; q < kCumB; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int i = 64 * r + lane; nx[q][r] = (i < fft_in[q]) ? x[q][i] : 0.0f; }
+    for (int base = 0; base < len_max; base += 256) {
+#pragma unroll
+        for (int q = 0; q < kCumB; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = nx[q][r];
+                sq[q * kCumRow + 64 * r + lane] = v * v;
+                const int i = base + 256 + 64 * r + lane;
+                nx[q][r] = (i < fft_in[q]) ? x[q][i] : 0.0f;
+            }
+        }
         wave_lds_fence();
-        if (lane == 0) {
-            // register blocks of 32 samples: the loads of a block do not wait for the stores of the previous
-            // one (separate input / output arrays), so only the dependent adds are on the critical path
-            const float4* in = reinterpret_cast<const float4*>(sq);
-            float4* outp = reinterpret_cast<float4*>(cs);
+        if (lane < kCumB && base < walk_len) {
+            // register blocks of 32 samples: the loads of a block do not wait for the stores of the previous one (separate
+            // input / output arrays), so only the dependent adds are on the critical path
+            const float4* in = reinterpret_cast<const float4*>(sq + lane * kCumRow);
+            float4* outp = reinterpret_cast<float4*>(cs + lane * kCumRow);
 #pragma unroll 2
             for (int blk = 0; blk < 8; ++blk) {
                 float4 v[8];
@@ -351,9 +374,14 @@ __global__ __launch_bounds__(64) void chirp_cumsum_kernel(ChirpArgs A) {
         }
         wave_lds_fence();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = base + 64 * q + lane;
-            if (i < fft_in) cum[i + 1] = cs[64 * q + lane];
+        for (int q = 0; q < kCumB; ++q) {
+            if (base < fft_in[q]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = base + 64 * r + lane;
+                    if (i < fft_in[q]) cum[q][i + 1] = cs[q * kCumRow + 64 * r + lane];
+                }
+            }
         }
         wave_lds_fence();
     }
@@ -587,16 +615,21 @@ struct LtsArgs {
     ria_lts_result* out;
 };
 
-__host__ __device__ inline int lts_lds_bytes() { return kLtsMaxSpan * 8 + kLtsMaxOffsets * 12 + 64; }
+// The analytic signal sits in LDS with one empty slot after every 8 samples (sample i at slot i + (i >> 3)): the coarse
+// search gives lane l the offset 8 l, so without the padding the 32 lanes of a half-wave read slots 64 bytes apart - four
+// bank groups, an 8-way conflict on every one of the 2 x 1152 reads of a correlation; padded they are 72 bytes apart and
+// cover all 64 banks.
+__host__ __device__ inline int lts_slot(int i) { return i + (i >> 3); }
+__host__ __device__ inline int lts_lds_bytes() { return (lts_slot(kLtsMaxSpan) + 8) * 8 + kLtsMaxOffsets * 12 + 64; }
 
 struct LtsCorr { float corr, pr, pi; };
 __device__ inline LtsCorr lts_corr_at(const float2* __restrict__ an, int rel, int offset, int n) {
     float pr = 0.0f, pi = 0.0f, e1 = 0.0f, e2 = 0.0f;
-    const float2* p1 = an + rel;
-    const float2* p2 = p1 + kLtsSym;
-    for (int k = 0; k < kLtsSym; ++k) {
-        if (offset + k + kLtsSym >= n) break;
-        const float2 s1 = p1[k], s2 = p2[k];
+    int kmax = n - kLtsSym - offset;                 // the reference leaves the loop at the first k with offset + k + 1152 >= n
+    kmax = kmax < 0 ? 0 : (kmax > kLtsSym ? kLtsSym : kmax);
+#pragma unroll 4
+    for (int k = 0; k < kmax; ++k) {
+        const float2 s1 = an[lts_slot(rel + k)], s2 = an[lts_slot(rel + k + kLtsSym)];
         const float a = s1.x, b = -s1.y, c = s2.x, d = s2.y;     // conj(s1) * s2
         pr += a * c - b * d;
         pi += a * d + b * c;
@@ -607,10 +640,14 @@ __device__ inline LtsCorr lts_corr_at(const float2* __restrict__ an, int rel, in
     return {fdiv(hypotf_glibc(pr, pi), den), pr, pi};
 }
 
-__global__ __launch_bounds__(256) void lts_sync_kernel(LtsArgs A) {
+// kLtsThreads: the noise-only search (4 symbols) has 576 candidate offsets, the connected one (8 symbols) 1152: 640 lanes take
+// them in one / two rounds, and ten waves per CU (the span's 118 KB of LDS allow one workgroup) hide the LDS latency of
+// the 2 x 1152 dependent reads per candidate that four waves could not
+constexpr int kLtsThreads = 640;
+__global__ __launch_bounds__(kLtsThreads) void lts_sync_kernel(LtsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2* an = reinterpret_cast<float2*>(smem);                         // analytic signal of [base, base + span)
-    float* ccorr = reinterpret_cast<float*>(an + kLtsMaxSpan);             // per coarse offset
+    float* ccorr = reinterpret_cast<float*>(an + lts_slot(kLtsMaxSpan) + 8);   // per coarse offset
     float* cpr = ccorr + kLtsMaxOffsets;
     float* cpi = cpr + kLtsMaxOffsets;
     __shared__ float sh_noise; __shared__ int sh_start;
@@ -636,7 +673,7 @@ __global__ __launch_bounds__(256) void lts_sync_kernel(LtsArgs A) {
     int signal_start = 0;
     if (in_noise) {   // first window of 64 samples whose rms exceeds the threshold (:243-258)
         const int lim = n - 2 * L;
-        for (int base = 0; base < lim; base += 256) {
+        for (int base = 0; base < lim; base += kLtsThreads) {
             const int i = base + tid;
             bool hit = false;
             if (i < lim) {
@@ -661,16 +698,16 @@ __global__ __launch_bounds__(256) void lts_sync_kernel(LtsArgs A) {
     int span = search_end + 2 * L - base;
     if (base + span > n) span = n - base;
     if (span < 0) span = 0;
-    for (int r = tid; r < span; r += 256) {
+    for (int r = tid; r < span; r += kLtsThreads) {
         const int i = base + r;
         float q = 0.0f;
         for (int k = 0; k < kLtsTaps; ++k) q += A.hilbert[k] * ((i - k >= 0) ? x[i - k] : 0.0f);
-        an[r] = make_float2((i - 32 >= 0) ? x[i - 32] : 0.0f, q);
+        an[lts_slot(r)] = make_float2((i - 32 >= 0) ? x[i - 32] : 0.0f, q);
     }
     __syncthreads();
     // coarse grid, step 8 (:279-316)
     const int K = (search_end > signal_start) ? (search_end - signal_start + 7) / 8 : 0;
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += kLtsThreads) {
         const LtsCorr c = lts_corr_at(an, 8 * k, signal_start + 8 * k, n);
         ccorr[k] = c.corr; cpr[k] = c.pr; cpi[k] = c.pi;
     }

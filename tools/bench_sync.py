@@ -33,8 +33,13 @@ def main():
     base.scatter_add_(1, idx, pt[None, :].expand(n, -1))
     t = timed(lambda: e.sync_zc(base, 0.3, 15))
     r = e.sync_zc(base, 0.3, 15)
+    # algorithmic work of ZCSync::detect on this shape: per root 113 coarse + 63 fine + 3 extra lags, 1016-term complex
+    # correlations with the received energy (11 flops per term), four roots
+    zc_flop = 4 * (113 + 63 + 3) * 1016 * 11
     res["zc"] = {"buffers": n, "samples": 4512, "ms": round(t * 1e3, 2), "preambles_per_s": round(n / t), "detected": int(r["detected"].sum()),
-                 "GBps_algorithmic": round(n * 4512 * 4 / t / 1e9, 2)}
+                 "GBps_algorithmic": round(n * 4512 * 4 / t / 1e9, 2),
+                 "roofline": {"bound": "valu", "achieved": round(n * zc_flop / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s fp32 vector (no FMA: contraction is off for bit-exactness, so half of the FMA peak is the ceiling)",
+                              "frac": round(n * zc_flop / t / 1e12 / 157.3, 4)}}
     # dual chirp: 57600-sample preamble in 120000-sample buffers
     ch = torch.from_numpy(e.chirp_preamble()).cuda()
     n = 2048
@@ -45,13 +50,24 @@ def main():
     t = timed(lambda: e.sync_chirp(buf, 0.15))
     r = e.sync_chirp(buf, 0.15)
     exact = int((r["up_chirp_start"] == offs).sum())
+    # the 131072-point transform pair of each of the two searches is 12 register-resident passes over a 1 MiB complex
+    # array (read + write): 24 MiB of cache-side traffic per buffer (the 64-buffer chunks stay inside the Infinity Cache)
+    fft_bytes = 12 * 2 * 131072 * 8
     res["chirp"] = {"buffers": n, "samples": 120000, "ms": round(t * 1e3, 2), "preambles_per_s": round(n / t), "success": int(r["success"].sum()),
-                    "up_start_exact": exact, "GBps_algorithmic": round(n * 120000 * 4 / t / 1e9, 2)}
+                    "up_start_exact": exact, "GBps_algorithmic": round(n * 120000 * 4 / t / 1e9, 2),
+                    "roofline": {"bound": "cache (Infinity Cache / L2) bandwidth of the FFT passes", "achieved": round(n * fft_bytes / t / 1e12, 2), "unit": "TB/s of FFT pass traffic over the whole call",
+                                 "peak": 8.0, "peak_note": "HBM peak for scale; the passes of a 64-buffer chunk (160 MiB) are served on-die",
+                                 "frac": round(n * fft_bytes / t / 1e12 / 8.0, 3)}}
     # LTS light sync on 21000-sample spans of noise (worst case: full search)
     n = 4000
     x = torch.randn((n, 21000), device="cuda") * 0.1
     t = timed(lambda: e.sync_lts(x, None, 0.5))
-    res["lts"] = {"buffers": n, "samples": 21000, "ms": round(t * 1e3, 2), "spans_per_s": round(n / t)}
+    # worst case (noise only): 1152 coarse offsets x 1152-term complex autocorrelation with both energies (14 flops per
+    # term, 32 B of LDS reads per term) + the 65-tap Hilbert filter over the span
+    lts_flop = 1152 * 1152 * 14 + 11520 * 65 * 2
+    res["lts"] = {"buffers": n, "samples": 21000, "ms": round(t * 1e3, 2), "spans_per_s": round(n / t),
+                  "roofline": {"bound": "lds", "achieved": round(n * 1152 * 1152 * 32 / t / 1e12, 2), "peak": round(256 * 256 * 2.4e9 / 1e12, 1), "unit": "TB/s of LDS reads (256 B/clk/CU)",
+                               "frac": round(n * 1152 * 1152 * 32 / t / (256 * 256 * 2.4e9), 4), "TFLOPs": round(n * lts_flop / t / 1e12, 2)}}
     # Schmidl-Cox (OFDM-COX searchForSync): 8064-sample preamble at a random offset of 30000-sample noisy buffers
     pre = torch.from_numpy(e.cox_preamble()).cuda()
     n = 2048
