@@ -441,7 +441,10 @@ inline void launch_channel(int kind, float snr_db, uint64_t seed, uint64_t first
 //   * mixing, the delayed tap and the AWGN add are one lane per sample; the signal power that scales the
 //     noise is a left-to-right sum over the frame (lane 0).
 // Output is bit-identical to the reference channel for the same (preset, SNR, seed).
-constexpr int kChanTile = 512, kChanNbuf = 5 * kChanTile + 704;
+#ifndef RIA_CHAN_TILE
+#define RIA_CHAN_TILE 64    // samples per tile: 9.5 KB of LDS per wave, 16 waves per CU; per 32 768 faded frames 512: 48 ms (5 waves per CU), 256: 29, 128: 24, 64: 20
+#endif
+constexpr int kChanTile = RIA_CHAN_TILE, kChanNbuf = 5 * kChanTile + 704;
 struct ChanExactArgs {
     float* samples; long long stride; int frame_samples; int n_frames;
     int fading, multipath, delay;
