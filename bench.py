@@ -362,7 +362,7 @@ def main(argv=None, engine_factory=None):
         }
         if world == 1 and not args.no_cpu_baseline and not args.steps_only:
             # bounded sample of the same workload: the last batch, as many of its frames as the host cores finish in ~20 s
-            res["cpu_baseline"] = cpu_baseline(batches[-1][:4096].cpu().numpy(), seconds_budget=20.0)
+            res["cpu_baseline"] = cpu_baseline(batches[-1][:24576].cpu().numpy(), seconds_budget=20.0)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
 step() { local name=$1; shift; "$@"; local rc=$?; echo "$name rc=$rc" | tee -a "$O/progress.log"; if [ $rc -ge 124 ]; then exit $rc; fi; }
 run_pytest() { timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$O/pytest_gpu.log" 2>&1; }
-run_latency() { timeout -k 10 300 python tools/bench_latency.py --out "$O/latency.json" > "$O/latency.log" 2>&1; }
+run_latency() { timeout -k 10 400 python tools/bench_latency.py --out "$O/latency.json" > "$O/latency.log" 2>&1; }
 run_smoke() { timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; }
 run_bench() { timeout -k 10 400 python bench.py > "$O/bench.log" 2>&1; }
 run_stats() { timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 bench.py --no-cpu-baseline > "$O/stats.log" 2>&1; }
