@@ -70,7 +70,10 @@ typedef struct ria_gpu_geometry {
     int32_t info_bits, bytes_per_codeword, info_bytes_per_frame; /* 324, 40, 160 */
     int32_t ldpc_max_iterations; /* ldpc_codec.hpp:86-95 */
     int32_t ldpc_edges;
-    int32_t reserved[2];
+    int32_t ldpc_k;              /* information bits of the LDPC code itself (ldpc_decoder.cpp:21-36): what the single-codeword
+                                    decoders return, ceil(ldpc_k / 8) bytes.  Equals info_bits except at R1/3, whose table entry
+                                    uses the (324, 324) code while the frame layer counts 216 bits (27 bytes) per codeword */
+    int32_t reserved[1];
 } ria_gpu_geometry;
 
 /* Per-frame input of the demodulator: the three setters the host calls before process()
@@ -155,7 +158,7 @@ int ria_gpu_decode_batch(ria_gpu_handle h, const float* llr_dev, int llr_stride,
                          uint32_t flags, uint8_t* info_out_dev, ria_decode_status* status_dev, void* stream);
 
 /* Single-codeword decoder (LDPCDecoder::decodeSoft, include/ultra/fec.hpp:48-81): n_cw rows of 648
- * LLRs already in decoder order; out: n_cw * ceil(k/8) bytes; ok/iters: n_cw entries. */
+ * LLRs already in decoder order; out: n_cw * ceil(ldpc_k/8) bytes (ria_gpu_geometry.ldpc_k); ok/iters: n_cw entries. */
 int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, int max_iterations,
                               float min_sum_factor, uint8_t* out_dev, uint8_t* ok_dev,
                               uint16_t* iters_dev, void* stream);
@@ -163,7 +166,7 @@ int ria_gpu_ldpc_decode_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, 
 /* robustDecodeSingleCW (src/gui/modem/streaming_decoder.cpp:1028-1058; the per-codeword decoder of the MC-DPSK and
  * control-frame paths, :1290,:1454,:2620): a fresh LDPCDecoder at getRecommendedIterations(rate), min-sum factor
  * 0.9375, then 0.875 / 0.75 / 0.625 / 0.5 until one converges.  n_cw rows of 648 LLRs in decoder order; out: n_cw *
- * ceil(k/8) bytes (the last attempt's hard bits; the reference returns them only when ok); tries_dev (nullable):
+ * ceil(ldpc_k/8) bytes (the last attempt's hard bits; the reference returns them only when ok); tries_dev (nullable):
  * decodes made, 1..5; iters_dev: lastIterations() of the last one. */
 int ria_gpu_ldpc_decode_robust_batch(ria_gpu_handle h, const float* llr_dev, int n_cw, uint8_t* out_dev, uint8_t* ok_dev,
                                      uint16_t* iters_dev, uint8_t* tries_dev, void* stream);

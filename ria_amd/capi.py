@@ -46,8 +46,8 @@ class Geometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("pilot_spacing", "n_pilots", "n_data_carriers", "bits_per_carrier",
                                           "bits_per_symbol", "n_data_symbols", "samples_per_symbol",
                                           "frame_samples", "llrs_per_frame", "info_bits", "bytes_per_codeword",
-                                          "info_bytes_per_frame", "ldpc_max_iterations", "ldpc_edges")] + \
-               [("reserved", C.c_int32 * 2)]
+                                          "info_bytes_per_frame", "ldpc_max_iterations", "ldpc_edges", "ldpc_k")] + \
+               [("reserved", C.c_int32 * 1)]
 
 
 class FrameMeta(C.Structure):

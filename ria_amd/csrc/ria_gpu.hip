@@ -468,6 +468,7 @@ int ria_gpu_create(const ria_gpu_config* cfg, ria_gpu_handle* out) {
     g.info_bytes_per_frame = 4 * g.bytes_per_codeword;
     g.ldpc_max_iterations = recommended_iterations(cfg->code_rate);
     g.ldpc_edges = h->code.n_edges;
+    g.ldpc_k = h->code.k;
 
 #define CREATE_TRY(expr)                                                                              \
     do {                                                                                              \
@@ -1417,7 +1418,7 @@ int ria_gpu_ldpc_decode_robust_host(ria_gpu_handle h, const float* llr_host, int
                                     uint16_t* iters_host, uint8_t* tries_host) {
     if (!h || !llr_host || !out_host || !ok_host || n_cw <= 0) return fail(h, RIA_ERR_INVALID, "ria_gpu_ldpc_decode_robust_host: bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t n = static_cast<size_t>(n_cw), nb = static_cast<size_t>((h->geo.info_bits + 7) / 8);
+    const size_t n = static_cast<size_t>(n_cw), nb = static_cast<size_t>((h->code.k + 7) / 8);
     const size_t b_llr = n * 648 * sizeof(float), o_out = up256(b_llr), o_ok = up256(o_out + n * nb), o_it = up256(o_ok + n), o_tr = up256(o_it + 2 * n);
     const size_t total = up256(o_tr + n);
     int rc = ensure_host_stage(h, total);

@@ -142,7 +142,7 @@ class RxEngine:
         """llr_rows: float32 [n_cw, 648] in decoder order."""
         n = llr_rows.shape[0]
         assert llr_rows.dtype == torch.float32 and llr_rows.is_contiguous() and llr_rows.shape[1] == 648
-        nb = (self.geo.info_bits + 7) // 8
+        nb = (self.geo.ldpc_k + 7) // 8
         out = torch.empty((n, nb), dtype=torch.uint8, device=self.device)
         ok = torch.empty(n, dtype=torch.uint8, device=self.device)
         it = torch.empty(n, dtype=torch.int16, device=self.device)
@@ -154,7 +154,7 @@ class RxEngine:
         """robustDecodeSingleCW over a batch: llr_rows float32 [n_cw, 648] -> (bytes, ok, iterations, tries)"""
         n = llr_rows.shape[0]
         assert llr_rows.dtype == torch.float32 and llr_rows.is_contiguous() and llr_rows.shape[1] == 648
-        nb = (self.geo.info_bits + 7) // 8
+        nb = (self.geo.ldpc_k + 7) // 8
         out = torch.empty((n, nb), dtype=torch.uint8, device=self.device)
         ok = torch.empty(n, dtype=torch.uint8, device=self.device)
         it = torch.empty(n, dtype=torch.int16, device=self.device)

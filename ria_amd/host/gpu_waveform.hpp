@@ -380,7 +380,7 @@ private:
 // robustDecodeSingleCW(llr, 648, rate) (streaming_decoder.cpp:1028-1058): the per-codeword decoder of the MC-DPSK and
 // control-frame paths - min-sum factor 0.9375, then 0.875 / 0.75 / 0.625 / 0.5 - on the GPU.  `gpu` must be bound to `rate`.
 inline std::pair<bool, Bytes> robustDecodeSingleCW(GpuHandle& gpu, const float* llr648, int* tries = nullptr) {
-    const int nb = (gpu.geo().info_bits + 7) / 8;
+    const int nb = (gpu.geo().ldpc_k + 7) / 8;
     Bytes out(static_cast<size_t>(nb));
     uint8_t ok = 0, tr = 0;
     if (ria_gpu_ldpc_decode_robust_host(gpu.get(), llr648, 1, out.data(), &ok, nullptr, &tr) != RIA_OK) return {false, Bytes()};

@@ -97,7 +97,7 @@ def test_ldpc_vectors_all_rates(golden):
     for r, rn in rates.items():
         e = engine("QAM16", rn)
         llr = dev(g[f"llr_{r}"])
-        nb = (e.geo.info_bits + 7) // 8
+        nb = (e.geo.ldpc_k + 7) // 8
         for c, (factor, mi) in enumerate(g["configs"]):
             out, ok, it = e.ldpc_decode(llr, int(mi), float(factor))
             ref = g[f"res_{r}"][:, c]
