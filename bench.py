@@ -33,7 +33,8 @@ CLOCK_HZ = 2.4e9                             # MI355X_MICROARCH.md: max clock
 VALU_PEAK_INSTS = 256 * 4 * CLOCK_HZ / 2     # wave64 VALU instructions/s: 1024 SIMD-32 units, 2 cycles per wave64 instruction (the guide's
                                              # wave-scheduling section; equals its 157.3 TFLOP/s vector peak); ONE wave alone issues every 4
 LDS_PEAK_CYCLES = 256 * CLOCK_HZ             # LDS-array cycles/s: one array per CU (SQ_LDS_IDX_ACTIVE counts its busy cycles)
-RECOVERY_STAGE = ("recovery_list_kernel", "recovery_stage1_kernel", "recovery_fill_kernel", "recovery_stage2_kernel")
+RECOVERY_STAGE = ("recovery_list_kernel", "recovery_stage1_kernel", "recovery_fill_kernel", "recovery_stage2_kernel", "decode_fault_kernel")
+DEMOD_STAGE = ("demod_fft_kernel", "demod_decide_kernel", "demod_walk_kernel", "demod_est_kernel", "demod_frames_kernel")
 DECODE_STAGE = ("fast_primary_kernel", "fast_mark_kernel", "fast_stage_kernel", "fast_phase0_kernel", "fast_chain_kernel",
                 "fast_cascade_kernel", "fast_finalize_kernel", "frame_validate_kernel", "dual_phase0_kernel", "dual_cascade_kernel")
 
@@ -273,9 +274,9 @@ def main(argv=None, engine_factory=None):
         step_s = elapsed / args.steps
         dec = t_decode >= t_demod
         dom = ("decode stage (fast_primary/mark/stage/phase0/chain/cascade/finalize + frame_validate + recovery_* kernels: one "
-               "ria_gpu_decode_batch call)") if dec else "demod_frames_kernel"
+               "ria_gpu_decode_batch call)") if dec else "demodulator (demod_fft/decide/walk/est kernels: one ria_gpu_demod_batch call)"
         dur_ms, algo = (t_decode, ALGO_BYTES_DECODE * B) if dec else (t_demod, ALGO_BYTES_DEMOD * B)
-        stage = (DECODE_STAGE + RECOVERY_STAGE) if dec else ("demod_frames_kernel",)
+        stage = (DECODE_STAGE + RECOVERY_STAGE) if dec else DEMOD_STAGE
         hbm_achieved = algo / (dur_ms * 1e-3) / 1e9
         # HBM traffic, LDS-array cycles and instruction counts cannot be measured from inside the process: they come from the
         # rocprofv3 --pmc passes of THIS command (tools/measure_round.sh) summarised under profiles/ - and only from a summary
@@ -287,7 +288,7 @@ def main(argv=None, engine_factory=None):
         tr, tr_path = matching_profile("_hbm_traffic_pmc.json", src)
         if tr is not None and tr["_meta"].get("frames_per_launch") == B:
             traffic = int(sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tr.items() if in_stage(k, stage)))
-            traffic_all = int(sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tr.items() if k != "_meta"))
+            traffic_all = int(sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tr.items() if in_stage(k, DEMOD_STAGE + DECODE_STAGE + RECOVERY_STAGE)))
             traffic_src = tr_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, RIA_NO_SPLIT: one launch = one whole step; FETCH_SIZE x2 for gfx950)"
         else:
             traffic_src = tr_path if tr is None else f"{tr_path} was measured at {tr['_meta'].get('frames_per_launch')} frames per launch, this run at {B}"
@@ -296,7 +297,7 @@ def main(argv=None, engine_factory=None):
             m = sq["_meta"]
             per_step = lambda field, names: sum(v[field] * v["launches"] for k, v in sq.items() if in_stage(k, names)) / m["steps_counted"]   # noqa: E731
             dec_insts = per_step("valu_insts", DECODE_STAGE + RECOVERY_STAGE)
-            all_insts = per_step("valu_insts", DECODE_STAGE + RECOVERY_STAGE + ("demod_frames_kernel",))
+            all_insts = per_step("valu_insts", DECODE_STAGE + RECOVERY_STAGE + DEMOD_STAGE)
             valu_issue = {"peak_insts_per_s": VALU_PEAK_INSTS, "unit": "wave64 VALU instructions (SQ_INSTS_VALU)",
                           "decode_stage": {"insts_per_step": int(dec_insts), "ms": round(t_decode, 3),
                                            "frac": round(dec_insts / (t_decode * 1e-3) / VALU_PEAK_INSTS, 4)},
@@ -332,7 +333,7 @@ def main(argv=None, engine_factory=None):
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": traffic}
         roof.update({"traffic_source": traffic_src, "hbm": hbm, "hbm_fused_step": hbm_fused, "lds": lds, "valu_issue": valu_issue,
-                     "kernel_ms": {"demod_frames_kernel": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
+                     "kernel_ms": {"demod_kernels": round(t_demod, 3), "decode_kernels": round(t_decode, 3)},
                      "limiter": "LDS array + FP32 VALU issue, not HBM (SURVEY.md 8d: the fused chain's compulsory traffic is 0.1 % of HBM peak at 1 M frames/s)",
                      "kernel_source_sha256": src})
 

@@ -947,18 +947,19 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_waves_per_eu(3
 }
 
 // =====================================================================================================
-// Split pipeline (the default): the same arithmetic in four kernels, so that the two halves of the work run
-// at the occupancy each wants instead of sharing one wave per frame.
-//   demod_lts_kernel   2 waves per frame: the two training symbols through the FFT with the caller's CFO, then the
-//                      residual-CFO decision of estimateChannelFromLTS (channel_equalizer.cpp:304-382) -> the frame's
-//                      final CFO; frames that keep their CFO also keep these two rows of bins
-//   demod_walk_kernel  1 lane per frame with a CFO: the serial float phase recurrence over the whole frame
-//                      (channel_equalizer.cpp:132-144), leaving its value at every 72nd sample
-//   demod_fft_kernel   1 wave per (frame, symbol): downconversion + 1024-point FFT of every symbol still missing,
-//                      massively parallel (16 x n_frames waves, no cross-symbol state), 59 bins per symbol to the
-//                      workspace (L2 / Infinity Cache resident: the host walks chunks of frames)
-//   demod_est_kernel   1 wave per frame, lane = carrier: the sequential estimator / equaliser / demapper over the
-//                      stored bins (latency-bound ordered sums and libm calls: few registers, many waves per SIMD)
+// Split pipeline (the default): the same arithmetic in separate kernels, so that the two halves of the work run
+// at the occupancy each wants instead of sharing one wave per frame.  Per chunk of frames:
+//   demod_walk_kernel(initial)  frames that arrive with a CFO: the serial phase recurrence over the two training symbols
+//   demod_fft_kernel(0, 2, 0)   the two training symbols with the caller's CFO
+//   demod_decide_kernel         1 wave per frame, lane = carrier: the residual-CFO decision of estimateChannelFromLTS
+//                               (channel_equalizer.cpp:304-382) -> the frame's final CFO; frames whose CFO changed are listed
+//   demod_walk_kernel(final)    1 lane per frame with a CFO: the serial float phase recurrence over the whole frame
+//                               (channel_equalizer.cpp:132-144), leaving its value at every 72nd sample
+//   demod_fft_kernel(2, n-2, 1) downconversion + 1024-point FFT of the data symbols; persistent waves, one symbol index per
+//                               wave, 59 bins per symbol to the workspace
+//   demod_fft_kernel(0, 2, 1, list)  the training symbols of the listed frames again (channel_equalizer.cpp:337-344)
+//   demod_est_kernel<MOD>       1 wave per frame, lane = carrier: the sequential estimator / equaliser / demapper over the
+//                               stored bins (latency-bound ordered sums and libm calls: few registers, many waves per SIMD)
 struct DemodWs {
     float2* Y;        // [chunk][n_sym][64]  the 59 used bins of every symbol (logical carrier order)
     float* cfo;       // [chunk]  CFO after the training estimate
