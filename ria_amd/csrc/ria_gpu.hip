@@ -56,6 +56,7 @@ struct ria_gpu {
     // transmitter-CFO impairment (cfo_kernels.hip.h): two complex arrays + the phase table, grown on demand
     void* d_txcfo_ws = nullptr; size_t txcfo_ws_bytes = 0;
     void* d_zc_ws = nullptr; size_t zc_ws_bytes = 0;   // baseband workspace of the long-buffer ZC search
+    float* d_chan_nstd = nullptr; int chan_nstd_frames = 0;   // per-frame noise sigma of the reference-identical channel
     // MC-DPSK: mixer tables per carrier count, Hilbert taps, CFO workspace
     std::map<int, void*> d_mc_carrier, d_mc_train;   // device modulator tables per carrier count
     std::map<int, void*> d_mc_mixer; void* d_mc_hilbert = nullptr; void* d_hilbert65 = nullptr; void* d_sync_host = nullptr; size_t sync_host_bytes = 0; void* d_mc_ws = nullptr; size_t mc_ws_floats = 0;
@@ -425,7 +426,7 @@ void ria_gpu_destroy(ria_gpu_handle h) {
     if (h->d_hilbert65) (void)hipFree(h->d_hilbert65);
     if (h->d_sync_host) (void)hipFree(h->d_sync_host);
     if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
-    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws, h->d_txcfo_ws, h->d_zc_ws}) if (p) (void)hipFree(p);
+    for (void* p : {h->d_cox_tI, h->d_cox_tQ, h->d_cox_ws, h->d_txcfo_ws, h->d_zc_ws, static_cast<void*>(h->d_chan_nstd)}) if (p) (void)hipFree(p);
     for (void* p : h->d_demod_ws) if (p) (void)hipFree(p);
     for (void* p : {(void*)h->d_rctl, (void*)h->d_flagged, (void*)h->d_list2, (void*)h->d_stage2, (void*)h->d_info_c, (void*)h->d_rows_c,
                     (void*)h->d_redec_ok, (void*)h->d_redec_bytes, (void*)h->d_st_c, (void*)h->d_overflow}) if (p) (void)hipFree(p);
@@ -933,6 +934,17 @@ int ria_gpu_channel_batch(ria_gpu_handle h, int kind, float snr_db, uint64_t see
     return RIA_OK;
 }
 
+// per-frame workspace of channel_power_kernel, grown on demand (a growth waits for the stream's earlier users of the old block)
+static int chan_ws(ria_gpu_handle h, int n_frames, hipStream_t s) {
+    if (n_frames <= h->chan_nstd_frames) return RIA_OK;
+    if (h->d_chan_nstd) { HIP_TRY(h, hipStreamSynchronize(s)); (void)hipFree(h->d_chan_nstd); }
+    h->d_chan_nstd = nullptr; h->chan_nstd_frames = 0;
+    const int cap = std::max(n_frames, 4096);
+    HIP_TRY(h, hipMalloc(&h->d_chan_nstd, static_cast<size_t>(cap) * sizeof(float)));
+    h->chan_nstd_frames = cap;
+    return RIA_OK;
+}
+
 int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32_t seed, uint64_t first_frame,
                                 float* samples_dev, int64_t stride, int frame_samples, int n_frames, void* stream) {
     if (!h || n_frames < 0 || kind < 0 || kind > 4 || frame_samples < 0 || stride < frame_samples)
@@ -940,7 +952,8 @@ int ria_gpu_channel_exact_batch(ria_gpu_handle h, int kind, float snr_db, uint32
     if (n_frames == 0 || frame_samples == 0) return RIA_OK;
     if (!samples_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_batch: null samples");
     HIP_TRY(h, hipSetDevice(h->device));
-    launch_channel_exact(kind, snr_db, seed, first_frame, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream));
+    if (int rc = chan_ws(h, n_frames, static_cast<hipStream_t>(stream))) return rc;
+    launch_channel_exact(kind, snr_db, seed, first_frame, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), h->d_chan_nstd);
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }
@@ -952,7 +965,8 @@ int ria_gpu_channel_exact_seeded_batch(ria_gpu_handle h, int kind, float snr_db,
     if (n_frames == 0 || frame_samples == 0) return RIA_OK;
     if (!samples_dev || !seeds_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_seeded_batch: null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    launch_channel_exact(kind, snr_db, 0u, 0u, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), seeds_dev);
+    if (int rc = chan_ws(h, n_frames, static_cast<hipStream_t>(stream))) return rc;
+    launch_channel_exact(kind, snr_db, 0u, 0u, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), h->d_chan_nstd, seeds_dev);
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
 }
@@ -965,7 +979,8 @@ int ria_gpu_channel_exact_cfo_batch(ria_gpu_handle h, int kind, float snr_db, co
     if (n_frames == 0 || frame_samples == 0) return RIA_OK;
     if (!samples_dev || !seeds_dev) return fail(h, RIA_ERR_INVALID, "ria_gpu_channel_exact_cfo_batch: null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    launch_channel_exact(kind, snr_db, 0u, 0u, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), seeds_dev,
+    if (int rc = chan_ws(h, n_frames, static_cast<hipStream_t>(stream))) return rc;
+    launch_channel_exact(kind, snr_db, 0u, 0u, samples_dev, stride, frame_samples, n_frames, static_cast<hipStream_t>(stream), h->d_chan_nstd, seeds_dev,
                          cfo_hz_dev, 0.0f, random_cfo_max_hz, actual_cfo_out_dev);
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;

@@ -437,9 +437,12 @@ inline void launch_channel(int kind, float snr_db, uint64_t seed, uint64_t first
 // sample in the order imag/real of tap 1, imag/real of tap 2, AWGN.  One wavefront per frame:
 //   * the normal stream is produced a twist (312 candidate pairs) at a time by all lanes, acceptance ranked
 //     with ballot prefix counts so that the accepted values land in draw order (as normal648_wave does);
-//   * the four fading recurrences f = (1-a) f + a n are independent serial chains: lanes 0..3 walk a tile;
-//   * mixing, the delayed tap and the AWGN add are one lane per sample; the signal power that scales the
-//     noise is a left-to-right sum over the frame (lane 0).
+//   * the four fading recurrences f = (1-a) f + a n are independent serial chains: all lanes form the driving terms
+//     a (ns n) of a tile, lanes 0..3 then walk it with two dependent operations per sample (16-byte LDS loads / stores);
+//   * mixing, the delayed tap and the AWGN add are one lane per sample; the signal power that scales the noise is a
+//     left-to-right sum over the whole frame, i.e. a chain of 18 432 dependent additions: channel_power_kernel runs it
+//     ahead of this kernel with one LANE per frame (64 frames per wave, tiles transposed through LDS), so that the chain
+//     costs one wave instruction per 64 frames instead of per frame.
 // Output is bit-identical to the reference channel for the same (preset, SNR, seed).
 #ifndef RIA_CHAN_TILE
 #define RIA_CHAN_TILE 64    // samples per tile: 9.5 KB of LDS per wave, 16 waves per CU; per 32 768 faded frames 512: 48 ms (5 waves per CU), 256: 29, 128: 24, 64: 20
@@ -451,6 +454,7 @@ struct ChanExactArgs {
     float alpha, one_minus_alpha, ns, g1, g2, noise_gain;
     uint32_t seed; uint64_t first_frame;
     const uint32_t* seeds;   // nullable: per-frame mt19937 seeds (then seed / first_frame are not used)
+    const float* nstd;       // [n_frames] noise sigma of every frame (channel_power_kernel)
     // CFO impairment of the channel object (hf_channel.hpp:47-51 Config::cfo_hz / random_cfo_max_hz, :97-102, :172-241)
     const float* cfo_hz;     // nullable: per-frame Config::cfo_hz (else cfo_all)
     float cfo_all;
@@ -458,6 +462,42 @@ struct ChanExactArgs {
     float* actual_cfo_out;   // nullable [n_frames]: getActualCFO()
 };
 __host__ __device__ inline int chan_exact_lds_bytes() { return 624 * 4 + kChanNbuf * 4 + 4 * kChanTile * 4 + kChanTile * 4 + 128 * 4 + 256 * 4 + 64; }
+
+// process() :115-131: signal power over the samples with |x| > 1e-6 (left to right), rms, noise sigma = rms * 10^(-snr/20).
+// One lane per frame: a wave takes 64 frames, 64 samples of each at a time, transposed through LDS (row stride 65).
+constexpr int kPowRow = 65;
+__global__ __launch_bounds__(64) void channel_power_kernel(const float* __restrict__ samples, long long stride, int n, int n_frames,
+                                                           float noise_gain, float* __restrict__ nstd) {
+    __shared__ float T[64 * kPowRow];
+    const int lane = threadIdx.x, f0 = blockIdx.x * 64;
+    const int rows = (n_frames - f0 < 64) ? n_frames - f0 : 64;
+    float power = 0.0f; int cnt = 0;
+    float xv[64];
+    auto fetch = [&](int base) {
+        const int i = base + lane;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) xv[r] = (r < rows && i < n) ? samples[static_cast<long long>(f0 + r) * stride + i] : 0.0f;
+    };
+    fetch(0);
+    for (int base = 0; base < n; base += 64) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) T[r * kPowRow + lane] = xv[r];
+        wave_sync();
+        if (base + 64 < n) fetch(base + 64);                // in flight during the chain below
+#pragma unroll 16
+        for (int i = 0; i < 64; ++i) {
+            const float v = T[lane * kPowRow + i];
+            const bool c = fabs_(v) > 1e-6f;                  // zero padding never passes
+            power += c ? v * v : 0.0f;                        // + (+0.0f) is exact: power is never -0.0
+            cnt += c ? 1 : 0;
+        }
+        wave_sync();
+    }
+    if (lane < rows) {
+        const float rms = cnt ? fsqrt(fdiv(power, static_cast<float>(cnt))) : 0.1f;
+        nstd[f0 + lane] = rms * noise_gain;
+    }
+}
 
 __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -469,21 +509,7 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
     float* tmp = hist + 128;                   // [256]
     const int lane = threadIdx.x, n = A.frame_samples;
     float* x = A.samples + static_cast<long long>(blockIdx.x) * A.stride;
-    // signal power over the non-zero samples (left-to-right), noise sigma
-    float power = 0.0f; int cnt = 0;
-    for (int base = 0; base < n; base += 256) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int i = base + 64 * q + lane; tmp[64 * q + lane] = (i < n) ? x[i] : 0.0f; }
-        wave_sync();
-        if (lane == 0) {
-            const int m = (n - base < 256) ? n - base : 256;
-            for (int i = 0; i < m; ++i) { const float v = tmp[i]; if (fabs_(v) > 1e-6f) { power += v * v; cnt++; } }
-        }
-        wave_sync();
-    }
-    power = __shfl(power, 0); cnt = __shfl(cnt, 0);
-    const float rms = cnt ? fsqrt(fdiv(power, static_cast<float>(cnt))) : 0.1f;
-    const float nstd = rms * A.noise_gain;
+    const float nstd = A.nstd[blockIdx.x];
     mt_seed_wave(st, A.seeds ? A.seeds[blockIdx.x] : A.seed + static_cast<uint32_t>(A.first_frame + blockIdx.x), lane);
     for (int i = lane; i < 128; i += 64) hist[i] = 0.0f;
     // The constructor's CFO draw (hf_channel.hpp:97-102) takes the generator's FIRST word, so the normal
@@ -501,7 +527,6 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
     int have = 0;
     const int per = A.fading ? 5 : 1;
     float fc = (lane == 0 || lane == 2) ? 1.0f : 0.0f;       // lanes 0..3: f1.re, f1.im, f2.re, f2.im
-    const int pick = (lane == 0) ? 1 : (lane == 1) ? 0 : (lane == 2) ? 3 : 2;   // imag is drawn before real
     for (int base = 0; base < n; base += kChanTile) {
         const int tn = (n - base < kChanTile) ? n - base : kChanTile;
         const int need = per * tn;
@@ -536,14 +561,35 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
         }
         for (int i = lane; i < tn; i += 64) xt[i] = x[base + i];
         wave_sync();
-        if (A.fading && lane < 4) {
-            for (int i = 0; i < tn; ++i) {
-                const float g = nbuf[5 * i + pick];
-                fc = A.one_minus_alpha * fc + A.alpha * (A.ns * g);
-                fr[lane * kChanTile + i] = fc;
+        if (A.fading) {
+            // driving terms alpha * (ns * g) of the four recurrences by all lanes, then lanes 0..3 walk their row in place
+            static_assert(kChanTile % 64 == 0 && kChanTile % 4 == 0, "tile = whole waves of samples");
+#pragma unroll
+            for (int q = 0; q < kChanTile / 64; ++q) {
+                const int i = 64 * q + lane;
+                if (i < tn) {
+                    const float g0 = nbuf[5 * i + 1], g1 = nbuf[5 * i], g2 = nbuf[5 * i + 3], g3 = nbuf[5 * i + 2];   // imag is drawn before real
+                    fr[i] = A.alpha * (A.ns * g0); fr[kChanTile + i] = A.alpha * (A.ns * g1);
+                    fr[2 * kChanTile + i] = A.alpha * (A.ns * g2); fr[3 * kChanTile + i] = A.alpha * (A.ns * g3);
+                }
             }
+            wave_sync();
+            if (lane < 4) {
+                float* row = fr + lane * kChanTile;
+                const float oma = A.one_minus_alpha;
+                int i = 0;
+                for (; i + 4 <= tn; i += 4) {
+                    float4 b = *reinterpret_cast<const float4*>(row + i);
+                    fc = oma * fc + b.x; b.x = fc;
+                    fc = oma * fc + b.y; b.y = fc;
+                    fc = oma * fc + b.z; b.z = fc;
+                    fc = oma * fc + b.w; b.w = fc;
+                    *reinterpret_cast<float4*>(row + i) = b;
+                }
+                for (; i < tn; ++i) { fc = oma * fc + row[i]; row[i] = fc; }
+            }
+            wave_sync();
         }
-        wave_sync();
         for (int i = lane; i < tn; i += 64) {
             const float sv = xt[i];
             float h1 = 1.0f, h2 = 1.0f;
@@ -632,7 +678,7 @@ __global__ __launch_bounds__(64) void channel_exact_kernel(ChanExactArgs A) {
 }
 
 inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t first_frame, float* samples, long long stride,
-                                 int frame_samples, int n_frames, hipStream_t s, const uint32_t* seeds = nullptr,
+                                 int frame_samples, int n_frames, hipStream_t s, float* nstd_ws, const uint32_t* seeds = nullptr,
                                  const float* cfo_hz = nullptr, float cfo_all = 0.0f, float random_cfo_max = 0.0f, float* actual_cfo_out = nullptr) {
     float delay_ms = 0, doppler = 0, g1 = 1.0f, g2 = 0.0f;  // presets hf_channel.hpp:411-488
     int fading = 1, multipath = 1;
@@ -655,6 +701,8 @@ inline void launch_channel_exact(int kind, float snr_db, uint32_t seed, uint64_t
     A.noise_gain = powf(10.0f, -snr_db / 20.0f);
     A.seed = seed; A.first_frame = first_frame; A.seeds = seeds;
     A.cfo_hz = cfo_hz; A.cfo_all = cfo_all; A.random_cfo_max = random_cfo_max; A.actual_cfo_out = actual_cfo_out;
+    A.nstd = nstd_ws;
+    hipLaunchKernelGGL(channel_power_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, samples, stride, frame_samples, n_frames, A.noise_gain, nstd_ws);
     hipLaunchKernelGGL(channel_exact_kernel, dim3(n_frames), dim3(64), chan_exact_lds_bytes(), s, A);
 }
 

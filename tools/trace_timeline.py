@@ -6,9 +6,9 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ria::", ""), r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows]
 ks.sort()
-# a step = one group of demod_frames_kernel launches (one per part); find the starts of demod groups
-dem = [k for k in ks if "demod_frames_kernel" in k[2]]
-# group demod launches that start within 2 ms of each other
+# a step starts with the demodulator kernels of its parts (demod_fft / decide / walk / est, or demod_frames with RIA_DEMOD_FUSED=1)
+dem = [k for k in ks if k[2].startswith("demod_")]
+# group demodulator launches that start within 30 ms of each other
 groups, cur = [], []
 for k in dem:
     if cur and k[0] - cur[-1][0] > 30e6:
