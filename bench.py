@@ -141,8 +141,8 @@ def main(argv=None, engine_factory=None):
     world_size 2 on gloo; None = the real engine on this rank's GPU."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=100000, help="frames per step per GPU (BASELINE.json configs[2]: 100k frames)")
     ap.add_argument("--channel", type=int, default=2, help="0 awgn 1 good 2 moderate 3 poor 4 flutter")
     ap.add_argument("--snr", type=float, default=20.0)

@@ -228,16 +228,23 @@ __device__ __forceinline__ FftLaneTw fft_load_lane_tw(const float2* __restrict__
         for (int q = 0; q < (1 << (s - 5)); ++q) L.ws[(1 << (s - 5)) - 1 + q] = tw[(a + 16 * q) << (10 - s)];
     return L;
 }
-template <bool kLaneTw = false>
+// Input tile in the bank-friendly order of the split pipeline: sample i of the symbol lives at fft_in_slot(i).  A lane of the
+// mixer holds samples 4 l .. 4 l + 3 of each quarter and stores them as two 16-byte pairs {e0, e2} and {e1, e3} whose
+// addresses are contiguous over the lanes (no bank conflict: the natural order puts the lanes' pairs 32 bytes apart, 2-way),
+// and pass 1's bit-reversed gather then reads 32 consecutive slots per half wave (natural order: every other slot, 2-way).
+__device__ __forceinline__ constexpr int fft_in_slot(int i) { return 2 * ((i >> 2) & 63) + ((i >> 1) & 1) + 128 * (i & 1) + 256 * (i >> 8); }
+template <bool kLaneTw = false, bool kSlotOrder = false>
 __device__ inline void fft1024_wave(float2* buf, const float2* __restrict__ tw, const FftUniformTw& utw, float2* Yrow, int lane, const FftLaneTw* ltw = nullptr) {
     float2 x[16];
     // pass 1: bit-reversed gather, stages 1-4 on indices 16*lane + r
     {
         int rl = __brev(static_cast<unsigned>(lane)) >> 26;  // 6-bit reverse
+        const int rs = 2 * (rl >> 2) + ((rl >> 1) & 1) + 128 * (rl & 1);   // fft_in_slot(rl + 64 r4) = rs + 32 (r4 & 3) + 256 (r4 >> 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int r4 = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
-            x[r] = buf[rl + 64 * r4];
+            if constexpr (kSlotOrder) x[r] = buf[rs + 32 * (r4 & 3) + 256 * (r4 >> 2)];
+            else x[r] = buf[rl + 64 * r4];
         }
     }
     wave_sync();
@@ -1071,7 +1078,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void de
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float2 m = make_float2(xv[4 * c + e] * ov[4 * c + e].x, xv[4 * c + e] * -ov[4 * c + e].y);
-                    tile[4 * lane + 256 * c + e] = cmul(m, cexpj(tv[e]));
+                    tile[2 * lane + 256 * c + (e >> 1) + 128 * (e & 1)] = cmul(m, cexpj(tv[e]));   // fft_in_slot(4 lane + 256 c + e)
                 }
                 wave_sync();
             }
@@ -1079,14 +1086,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void de
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    tile[4 * lane + 256 * c + e] = make_float2(xv[4 * c + e] * ov[4 * c + e].x, xv[4 * c + e] * -ov[4 * c + e].y);   // samples[i] * conj(osc)
+                for (int e = 0; e < 4; ++e)   // samples[i] * conj(osc) at fft_in_slot(i), i = 4 lane + 256 c + e
+                    tile[2 * lane + 256 * c + (e >> 1) + 128 * (e & 1)] = make_float2(xv[4 * c + e] * ov[4 * c + e].x, xv[4 * c + e] * -ov[4 * c + e].y);
         }
         i += F;
         const bool more = i < count;
         if (more) { q = list ? list[i] : i; fetch(q, xn); }   // in flight during the whole transform below
         wave_sync();
-        fft1024_wave<true>(tile, A.twiddle, utw, Yl, lane, &ltw);
+        fft1024_wave<true, true>(tile, A.twiddle, utw, Yl, lane, &ltw);
         S.ws.Y[(static_cast<size_t>(qc) * S.n_sym + s) * 64 + lane] = Yl[lane];
         if (!more) break;
         wave_sync();
