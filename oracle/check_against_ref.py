@@ -242,6 +242,26 @@ def main():
                     worst = f"{name} kind={kind} cfo={cfo} random_max={rmax}"
     check("WattersonChannel cfo_hz / random_cfo_max_hz + applyCFO (3 inputs x 5 presets x 7 settings)", ok, worst)
 
+    # the scenarios of the reference's own test programs (tools/test_zc_sync.cpp, test_spreading.cpp, test_chase_cache.cpp):
+    # restatement vs the builders that call the reference (oracle/ref_shim_tools.cpp); gen_golden.py additionally runs the
+    # programs themselves (make -C oracle tools) and compares what they print with those builders
+    zo, zr = O.tool_zc_cases(), R.tool_zc_cases()
+    check("tools/test_zc_sync.cpp scenarios (50 signals + ZCSyncResult)", all(
+        (bits_equal(zo[k], zr[k]) if zo[k].dtype == np.float32 else np.array_equal(zo[k], zr[k])) for k in zo))
+    ok, worst = True, ""
+    for m in (0, 2, 4):
+        for snr in (-16.0, -14.0, -12.0, -10.0, -8.0, -6.0, -4.0, -2.0, 0.0):
+            for t in range(20):
+                a, b = O.tool_spreading_case(snr, m, 1000 + t), R.tool_spreading_case(snr, m, 1000 + t)
+                same = (np.array_equal(a["tx"], b["tx"]) and bits_equal(a["frame"], b["frame"]) and bits_equal(a["soft"], b["soft"])
+                        and a["ok"] == b["ok"] and np.array_equal(a["decoded"], b["decoded"]) and a["bit_errors"] == b["bit_errors"])
+                ok &= same
+                if not same and not worst:
+                    worst = f"spreading={m} snr={snr} seed={1000 + t}"
+    check("tools/test_spreading.cpp testAtSNR (3 modes x 9 SNRs x 20 trials: frame, soft bits, decode)", ok, worst)
+    (lo, oo), (lr, orr) = O.tool_chase_llrs(), R.tool_chase_llrs()
+    check("tools/test_chase_cache.cpp receptions and decodes (400 codewords, 350 decodes)", bits_equal(lo, lr) and np.array_equal(oo, orr))
+
     print("\n%s: %d failing group(s)" % ("PINNED" if fails == 0 else "MISMATCH", fails))
     return 1 if fails else 0
 

@@ -11,7 +11,10 @@ Stage taps per frame: payload -> frame info bytes -> inte
 CFO, fading index) -> decodeFixedFrame status and bytes.
 """
 import os
+import re
+import subprocess
 import sys
+import zlib
 
 import numpy as np
 
@@ -432,6 +435,72 @@ def mcwf_fixture(R):
     return rec
 
 
+TOOL_SNRS = (-16.0, -14.0, -12.0, -10.0, -8.0, -6.0, -4.0, -2.0, 0.0)   # tools/test_spreading.cpp:166
+TOOL_MODES = (0, 2, 4)                                                    # NONE, TIME_2X, TIME_4X (:181-185)
+TOOL_TRIALS = 20                                                          # seeds 1000 + trial (:167,:198)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def run_tool(name):
+    """run one of the reference's own test programs (compiled unmodified by `make -C oracle tools`) and return its stdout"""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "tools", name)
+    return subprocess.run([exe], capture_output=True, text=True, check=False, timeout=600).stdout
+
+
+def tool_tables_fixture(R):
+    """The scenarios of the reference's own test programs for this path (tools/test_zc_sync.cpp, tools/test_spreading.cpp,
+    tools/test_chase_cache.cpp), rebuilt by oracle/ref_shim_tools.cpp, with the reference's results; the programs are also run
+    and what they print (correlations, pass counts, the success table) is checked against the rebuilt scenarios and recorded.
+    Inputs are recorded as CRC-32 only: the restatement regenerates them anywhere (tests/test_oracle_golden.py)."""
+    rec = {}
+    z = R.tool_zc_cases()
+    rec["zc_crc"] = np.array([crc(z["signals"][i, :z["lengths"][i]]) for i in range(len(z["lengths"]))], np.uint32)
+    for k in ("lengths", "test", "type", "param", "res7"):
+        rec["zc_" + k] = z[k]
+    passed = (z["res7"][:, 0] == 1) & (z["res7"][:, 1] == z["type"])
+    txt = run_tool("test_zc_sync")
+    printed = [float(v) for v in re.findall(r"\(.*corr=([-0-9.]+)", txt)]          # the PASS / FAIL lines of tests 0-3
+    assert len(printed) == 30 and all(abs(a - float(b)) < 0.00051 for a, b in zip(printed, z["res7"][:30, 3])), "test_zc_sync correlations"
+    counts = [int(passed[(z["test"] == t)].sum()) for t in range(5)]
+    cfo_ok = int((passed & (np.abs(z["res7"][:, 4] - z["param"]) < 5.0))[z["test"] == 3].sum())   # test 3 also wants |cfo error| < 5 Hz
+    counts[3] = cfo_ok
+    tool_counts = [int(a) for a, b in re.findall(r"Result: (\d+)/(\d+)", txt)]
+    assert tool_counts == counts, (tool_counts, counts)
+    rec["zc_tool_pass_counts"] = np.array(counts, np.int32)
+    # ---- test_spreading
+    shp = (len(TOOL_MODES), len(TOOL_SNRS), TOOL_TRIALS)
+    rec["sp_frame_crc"] = np.zeros(shp, np.uint32); rec["sp_soft_crc"] = np.zeros(shp, np.uint32)
+    rec["sp_decoded"] = np.zeros(shp + (40,), np.uint8); rec["sp_bit_errors"] = np.zeros(shp, np.int32); rec["sp_ok"] = np.zeros(shp, np.uint8)
+    rec["sp_tx"] = np.zeros((TOOL_TRIALS, 40), np.uint8); rec["sp_n_soft"] = np.zeros(len(TOOL_MODES), np.int32)
+    for mi, m in enumerate(TOOL_MODES):
+        for si, snr in enumerate(TOOL_SNRS):
+            for t in range(TOOL_TRIALS):
+                c = R.tool_spreading_case(snr, m, 1000 + t)
+                rec["sp_frame_crc"][mi, si, t] = crc(c["frame"]); rec["sp_soft_crc"][mi, si, t] = crc(c["soft"])
+                rec["sp_decoded"][mi, si, t] = c["decoded"]; rec["sp_bit_errors"][mi, si, t] = c["bit_errors"]; rec["sp_ok"][mi, si, t] = c["ok"]
+                rec["sp_tx"][t] = c["tx"]; rec["sp_n_soft"][mi] = len(c["soft"])
+    table = ((rec["sp_ok"] == 1) & (rec["sp_bit_errors"] == 0)).sum(axis=2).astype(np.int32)
+    txt = run_tool("test_spreading")
+    printed = np.array([int(a) for a in re.findall(r"\|\s+(\d+)/20 \|", txt)], np.int32).reshape(len(TOOL_MODES), len(TOOL_SNRS))
+    assert np.array_equal(printed, table), (printed, table)
+    rec["sp_tool_success_table"] = table
+    rec["sp_snrs"] = np.array(TOOL_SNRS, np.float32); rec["sp_modes"] = np.array(TOOL_MODES, np.int32)
+    # ---- test_chase_cache
+    l, ok = R.tool_chase_llrs()
+    rec["chase_llr_crc"] = np.array([crc(v) for v in l], np.uint32)
+    rec["chase_ok"] = ok
+    t2 = ok[:200].reshape(100, 2).sum(0); t3 = ok[200:].reshape(50, 3).sum(0)
+    txt = run_tool("test_chase_cache")
+    printed = [int(a) for a in re.findall(r":\s+(\d+)/(?:100|50) \(", txt)]
+    assert printed == [int(t2[0]), int(t2[1]), int(t3[0]), int(t3[1]), int(t3[2])], (printed, t2, t3)
+    rec["chase_tool_counts"] = np.array(printed, np.int32)
+    print("tool tables: zc", counts, "spreading", table.tolist(), "chase", printed)
+    return rec
+
+
 def main():
     if not po.Ref.available():
         print("needs oracle/_ref/libria_ref.so (make -C oracle ref)")
@@ -487,6 +556,9 @@ def main():
         return 0
     if only == "cfo":
         np.savez_compressed(os.path.join(OUT, "cfo_impairment.npz"), **cfo_fixture(R))
+        return 0
+    if only == "tools":
+        np.savez_compressed(os.path.join(OUT, "ref_tool_tables.npz"), **tool_tables_fixture(R))
         return 0
     if only == "burst":
         np.savez_compressed(os.path.join(OUT, "burst_chain.npz"), **burst_fixture(R, O))
@@ -564,6 +636,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "harq_trials.npz"), **harq_fixture(R))
     np.savez_compressed(os.path.join(OUT, "cfo_impairment.npz"), **cfo_fixture(R))
     np.savez_compressed(os.path.join(OUT, "mcdpsk_waveform.npz"), **mcwf_fixture(R))
+    np.savez_compressed(os.path.join(OUT, "ref_tool_tables.npz"), **tool_tables_fixture(R))
     print("done ->", OUT)
     return 0
 

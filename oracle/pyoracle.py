@@ -52,6 +52,10 @@ class Ldpc(C.Structure):
                 ("row_ptr", C.c_int * (CW_BITS + 1)), ("edge_var", C.c_int * MAX_EDGES)]
 
 
+class Mt(C.Structure):   # ro_mt: std::mt19937
+    _fields_ = [("s", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
 class RxAux(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "snr_db", "cfo_hz", "fading_index", "noise_variance", "lts_phase_slope", "snr_linear",
@@ -96,6 +100,12 @@ class Oracle:
         L.ro_channel_cfo.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_float, C.c_float, _f, C.c_int, _f, _f]
         L.ro_apply_tx_cfo.argtypes = [_f, C.c_int, C.c_float, _f, _f]
         L.ro_ldpc_decode.argtypes = [C.POINTER(Ldpc), _f, C.c_int, C.c_int, C.c_float, _u8, _i]
+        L.ro_mt_seed.argtypes = [C.POINTER(Mt), C.c_uint32]
+        L.ro_mt_next.argtypes = [C.POINTER(Mt)]
+        L.ro_mt_next.restype = C.c_uint32
+        L.ro_tool_add_noise.argtypes = [_f, C.c_int, C.c_float, C.POINTER(Mt)]
+        L.ro_tool_apply_cfo.argtypes = [_f, C.c_int, C.c_float, C.c_float]
+        L.ro_tool_chase_reception.argtypes = [_u8, C.c_float, C.POINTER(Mt), _f]
         L.ro_decode_fixed_frame.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8, _u8, _i, _i]
         L.ro_crc16.restype = C.c_uint16
         L.ro_zc_generate.argtypes = [C.c_int, _f, C.c_int]
@@ -334,6 +344,85 @@ class Oracle:
                                        ip(iters), ip(att))
         return data, ok, iters, att
 
+    # ---- the scenarios of the reference's own test programs, composed from the restatement (the compiled reference gives the
+    # same arrays through Ref.tool_*: oracle/ref_shim_tools.cpp)
+    ZC_TOOL_ROOTS = (1, 3, 5, 7)   # ZCFrameType PING, PONG, DATA, CONTROL (tools/test_zc_sync.cpp:313-323)
+
+    def _rng(self, seed):
+        m = Mt()
+        self.lib.ro_mt_seed(C.byref(m), seed & 0xFFFFFFFF)
+        return m
+
+    def tool_add_noise(self, x, snr_db, rng):
+        x = np.ascontiguousarray(x, np.float32).copy()
+        self.lib.ro_tool_add_noise(fp(x), len(x), snr_db, C.byref(rng))
+        return x
+
+    def tool_zc_cases(self):
+        """tools/test_zc_sync.cpp tests 0-4 (seed 42) -> dict(signals [50][4512], lengths, test, type, param, res7)"""
+        pre = [self.zc_generate(r) for r in self.ZC_TOOL_ROOTS]
+        pad = lambda t, n: np.concatenate([np.zeros(n, np.float32), pre[t], np.zeros(n, np.float32)])
+        cases = []
+        for t in range(4):
+            cases.append((0, t, 0.0, pad(t, 500)))
+        rng = self._rng(42)
+        for t in range(4):
+            cases.append((1, t, 20.0, self.tool_add_noise(pad(t, 1000), 20.0, rng)))
+        snr = np.float32(-15.0)
+        while snr <= np.float32(20.0):
+            cases.append((2, 0, float(snr), self.tool_add_noise(pad(0, 500), float(snr), self._rng(42))))
+            snr = np.float32(snr + np.float32(2.5))
+        for cfo in (-15.0, -10.0, -5.0, 0.0, 5.0, 10.0, 15.0):
+            x = pad(2, 500)
+            self.lib.ro_tool_apply_cfo(fp(x), len(x), cfo, 48000.0)
+            cases.append((3, 2, cfo, self.tool_add_noise(x, 15.0, self._rng(42))))
+        for trial in range(5):
+            for t in range(4):
+                cases.append((4, t, 10.0, self.tool_add_noise(pad(t, 500), 10.0, self._rng(42 + trial * 100 + t))))
+        n = len(cases)
+        sig = np.zeros((n, 4512), np.float32)
+        for i, c in enumerate(cases):
+            sig[i, :len(c[3])] = c[3]
+        res = np.stack([self.zc_detect(c[3], 0.2) for c in cases])
+        return dict(signals=sig, lengths=np.array([len(c[3]) for c in cases], np.int32), test=np.array([c[0] for c in cases], np.int32),
+                    type=np.array([c[1] for c in cases], np.int32), param=np.array([c[2] for c in cases], np.float32), res7=res)
+
+    def tool_spreading_case(self, snr_db, spreading, seed):
+        """tools/test_spreading.cpp testAtSNR: LDPCCodec::decode sees 650 soft bits, so LDPCDecoder::decodeSoft takes its
+        multi-block branch (ldpc_decoder.cpp:305-392): the first 648 through min-sum at the decoder's DEFAULT factor 0.75 for
+        up to 80 iterations, the hard decisions kept whether or not it converged (the program then only counts bit errors)"""
+        rng = self._rng(seed)
+        tx = np.array([self.lib.ro_mt_next(C.byref(rng)) & 0xFF for _ in range(40)], np.uint8)
+        coded = self.ldpc_encode(R1_2, tx)
+        sp = spreading if spreading in (2, 4) else 1
+        frame = self.tool_add_noise(self.mcdpsk_modulate(10, 1, sp, coded), snr_db, rng)
+        soft, _ = self.mcdpsk_demod(10, 1, sp, frame, 0.0, 0.0)
+        _, dec, _ = self.ldpc_decode(R1_2, soft[:648], 80, 0.75)
+        # the two soft bits beyond 648 go through decodeBP as a zero-padded block of their own (:394-406), and THAT decode's
+        # verdict is what lastDecodeSuccess() reports for the call
+        tail = np.zeros(648, np.float32); tail[:len(soft) - 648] = soft[648:]
+        ok = int(self.ldpc_decode(R1_2, tail, 80, 0.75)[0]) if len(soft) > 648 else 1
+        errs = int(np.unpackbits(dec[:40] ^ tx).sum()) if ok else 0
+        return dict(tx=tx, frame=frame, soft=soft, decoded=dec[:40].copy() if ok else np.zeros(40, np.uint8), ok=ok, bit_errors=errs)
+
+    def tool_chase_llrs(self):
+        """tools/test_chase_cache.cpp tests 2-3 -> (llrs [400][648], ok [350]): LDPCCodec::decode of 648 soft bits is
+        decodeBP at the decoder's default factor 0.75, 80 iterations"""
+        coded = self.ldpc_encode(R1_2, np.arange(40, dtype=np.uint8))
+        rng = self._rng(42)
+        l = np.zeros((400, 648), np.float32)
+        for i in range(400):
+            self.lib.ro_tool_chase_reception(up(coded), 2.5 if i < 200 else 1.5, C.byref(rng), fp(l[i]))
+        dec = lambda v: 1 if self.ldpc_decode(R1_2, np.ascontiguousarray(v, np.float32), 80, 0.75)[0] else 0
+        ok = []
+        for t in range(100):
+            a, b = l[2 * t], l[2 * t + 1]
+            ok += [dec(a), dec(a + b)]
+        for t in range(50):
+            a, b, c, d = l[200 + 4 * t: 204 + 4 * t]
+            ok += [dec(a), dec(a + b), dec(((a + b) + c) + d)]
+        return l, np.array(ok, np.uint8)
+
     def gather_table(self, bps, use_channel=True):
         t = np.zeros(4 * CW_BITS, np.int32)
         self.lib.ro_rx_gather_table(bps, int(use_channel), ip(t))
@@ -387,7 +476,36 @@ class Ref:
         L.ref_rx_close.argtypes = [C.c_void_p]
         L.ref_rx_close.restype = None
         L.ref_rx_frame.argtypes = [C.c_void_p, _f, C.c_int, C.c_float, _u8, _u8, _f, C.c_int]
+        L.ref_tool_zc_cases.argtypes = [_f, C.c_int, _i, _i, _i, _f, _f, C.c_int]
+        L.ref_tool_spreading_case.argtypes = [C.c_float, C.c_int, C.c_uint32, _u8, _f, C.c_int, _i, _f, C.c_int, _u8, _i]
+        L.ref_tool_chase_llrs.argtypes = [_f, _u8]
         L.ref_quiet()
+
+    # ---- the scenarios of the reference's own test programs (oracle/ref_shim_tools.cpp)
+    def tool_zc_cases(self):
+        """tools/test_zc_sync.cpp tests 0-4 -> dict(signals [50][4512], lengths, test, type, param, res7)"""
+        n_max, stride = 64, 4512
+        sig = np.zeros((n_max, stride), np.float32)
+        ln = np.zeros(n_max, np.int32); te = np.zeros(n_max, np.int32); ty = np.zeros(n_max, np.int32)
+        pa = np.zeros(n_max, np.float32); res = np.zeros((n_max, 7), np.float32)
+        n = self.lib.ref_tool_zc_cases(fp(sig), stride, ip(ln), ip(te), ip(ty), fp(pa), fp(res), n_max)
+        assert n > 0, n
+        return dict(signals=sig[:n].copy(), lengths=ln[:n].copy(), test=te[:n].copy(), type=ty[:n].copy(), param=pa[:n].copy(), res7=res[:n].copy())
+
+    def tool_spreading_case(self, snr_db, spreading, seed):
+        """tools/test_spreading.cpp testAtSNR -> dict(tx, frame, sizes, soft, decoded, ok, bit_errors)"""
+        frame = np.zeros(160000, np.float32); soft = np.zeros(1024, np.float32)
+        tx = np.zeros(40, np.uint8); dec = np.zeros(40, np.uint8); sizes = np.zeros(3, np.int32); out3 = np.zeros(3, np.int32)
+        n = self.lib.ref_tool_spreading_case(snr_db, spreading, seed, up(tx), fp(frame), len(frame), ip(sizes), fp(soft), len(soft), up(dec), ip(out3))
+        assert n > 0, n
+        return dict(tx=tx, frame=frame[:n].copy(), sizes=sizes, soft=soft[:out3[2]].copy(), decoded=dec, ok=int(out3[0]), bit_errors=int(out3[1]))
+
+    def tool_chase_llrs(self):
+        """tools/test_chase_cache.cpp tests 2-3 -> (llrs [400][648], ok [350])"""
+        l = np.zeros((400, 648), np.float32); ok = np.zeros(100 * 2 + 50 * 3, np.uint8)
+        n = self.lib.ref_tool_chase_llrs(fp(l), up(ok))
+        assert n == 400, n
+        return l, ok
 
     def channel_cfo(self, kind, snr_db, seed, x, cfo_hz=0.0, random_cfo_max_hz=0.0):
         x = np.ascontiguousarray(x, np.float32)

@@ -131,6 +131,16 @@ int ro_detect_data_sync(const float* x, int n, float known_cfo_hz, float thresho
 /* SimulatedChannel::applyTxCFO (tools/cli_simulator.cpp:298-341): the simulator's transmitter frequency offset - FFT of
  * the next power of two, frequency-domain Hilbert, inverse FFT, rotation by a wrapped float phase (in/out), real part */
 int ro_apply_tx_cfo(const float* in, int n, float cfo_hz, float* phase_inout, float* out);
+/* ---- helper arithmetic of the reference's own test programs (their scenarios are composed in pyoracle.py)
+ * ro_tool_add_noise: addNoise of tools/test_zc_sync.cpp:22-39 == tools/test_spreading.cpp:15-30 (AWGN at an SNR against the
+ *   mean power of ALL samples; a fresh std::normal_distribution<float>(0, sigma) per call on the caller's generator)
+ * ro_tool_apply_cfo: applyCFO of tools/test_zc_sync.cpp:43-63 (HilbertTransform(127), src/dsp/filters.cpp:266-317, rotation
+ *   by a float phase wrapped into (-pi, pi], real part)
+ * ro_tool_chase_reception: generateNoisyCodeword + addNoise of tools/test_chase_cache.cpp:21-62 (coded bits as +-4, a
+ *   reception is 2 (sign + n) snr with n ~ N(0, 1 / snr)) */
+void ro_tool_add_noise(float* x, int n, float snr_db, ro_mt* rng);
+void ro_tool_apply_cfo(float* x, int n, float cfo_hz, float sample_rate);
+void ro_tool_chase_reception(const uint8_t* coded81, float snr_db, ro_mt* rng, float* llr648);
 /* fec::ChaseCache::store arithmetic for one codeword slot (src/fec/chase_cache.cpp:27-88) */
 int ro_chase_store(float* existing, int* combine_count, int decoded, const float* soft);
 

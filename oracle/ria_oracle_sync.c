@@ -935,3 +935,59 @@ int ro_apply_tx_cfo(const float* in, int n, float cfo_hz, float* phase_inout, fl
     free(f); free(tw);
     return n;
 }
+
+/* ------------------------------------------------------------------ helper arithmetic of the reference's test programs */
+void ro_tool_add_noise(float* x, int n, float snr_db, ro_mt* rng) { /* tools/test_zc_sync.cpp:22-39 */
+    float sig_power = 0.0f;
+    for (int i = 0; i < n; ++i) sig_power += x[i] * x[i];
+    sig_power /= (float)n;                                  /* size_t -> float */
+    float snr_linear = powf(10.0f, snr_db / 10.0f);
+    float noise_power = sig_power / snr_linear;
+    float noise_std = sqrtf(noise_power);
+    ro_normal nd = {0.0f, 0};
+    for (int i = 0; i < n; ++i) x[i] += ro_normal_draw(&nd, rng, 0.0f, noise_std);
+}
+
+void ro_tool_apply_cfo(float* x, int n, float cfo_hz, float sample_rate) { /* tools/test_zc_sync.cpp:43-63 */
+    if (fabsf(cfo_hz) < 0.01f || n < 128) return;
+    enum { TAPS = 127, M = 63 };
+    float coeff[TAPS];
+    for (int k = 0; k < TAPS; ++k) {                        /* filters.cpp:266-291 */
+        int kk = k - M;
+        if (kk == 0) coeff[k] = 0;
+        else if (kk % 2 != 0) coeff[k] = (float)(2.0f / (M_PI * kk));
+        else coeff[k] = 0;
+        float w = (float)(2.0f * M_PI * k / (TAPS - 1));
+        coeff[k] *= 0.42f - 0.5f * cosf(w) + 0.08f * cosf(2.0f * w);
+    }
+    float* ar = (float*)malloc(sizeof(float) * (size_t)n);
+    float* ai = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) {                           /* filters.cpp:293-317: newest sample first */
+        float q = 0;
+        for (int k = 0; k < TAPS; ++k) q += coeff[k] * ((i - k >= 0) ? x[i - k] : 0.0f);
+        ar[i] = (i - M >= 0) ? x[i - M] : 0.0f;
+        ai[i] = q;
+    }
+    float phase = 0.0f;
+    float phase_inc = (float)(2.0f * M_PI * cfo_hz / sample_rate);
+    for (int i = 0; i < n; ++i) {
+        float rc = cosf(phase), rs = sinf(phase);
+        x[i] = ar[i] * rc - ai[i] * rs;                     /* real part of analytic * rotation */
+        phase += phase_inc;
+        while (phase > M_PI) phase = (float)(phase - 2.0f * M_PI);
+        while (phase < -M_PI) phase = (float)(phase + 2.0f * M_PI);
+    }
+    free(ar); free(ai);
+}
+
+void ro_tool_chase_reception(const uint8_t* coded81, float snr_db, ro_mt* rng, float* llr648) { /* tools/test_chase_cache.cpp:21-62 */
+    for (int i = 0; i < 648; ++i) llr648[i] = ((coded81[i >> 3] >> (7 - (i & 7))) & 1) ? -4.0f : 4.0f;
+    float snr_linear = powf(10.0f, snr_db / 10.0f);
+    float noise_std = 1.0f / sqrtf(snr_linear);
+    ro_normal nd = {0.0f, 0};
+    for (int i = 0; i < 648; ++i) {
+        float sign = (llr648[i] > 0) ? 1.0f : -1.0f;
+        float received = sign + ro_normal_draw(&nd, rng, 0.0f, noise_std);
+        llr648[i] = 2.0f * received * snr_linear;
+    }
+}

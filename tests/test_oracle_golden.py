@@ -452,3 +452,63 @@ def test_mcdpsk_waveform_oracle_matches_reference_golden(oracle, golden):
             assert [int(ok), it, tries] == list(dec[:3]) and np.array_equal(out[:20], dec[3:23].astype(np.uint8)), case
             n_ok += int(ok and np.array_equal(out[:20], info[:20]))
     assert n_ok >= 7
+
+
+# ---- the reference's own test programs (tools/test_zc_sync.cpp, tools/test_spreading.cpp, tools/test_chase_cache.cpp)
+def crc32(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def test_reference_test_programs_zc_sync_scenarios(oracle, golden):
+    """tools/test_zc_sync.cpp tests 0-4 (silence, 20 dB, the -15 ... 20 dB sweep, CFO -15 ... 15 Hz, 20 discrimination trials),
+    composed from the restatement: the signals are the reference's (CRC-32 recorded from oracle/ref_shim_tools.cpp, which builds
+    them with the library's own mt19937 / normal_distribution and the reference's HilbertTransform), every ZCSyncResult field
+    is the reference's, and the program's own verdicts hold (its printed pass counts were recorded while the fixture was made)"""
+    g = golden("ref_tool_tables")
+    z = oracle.tool_zc_cases()
+    assert np.array_equal(z["lengths"], g["zc_lengths"]) and np.array_equal(z["test"], g["zc_test"]) and np.array_equal(z["type"], g["zc_type"])
+    for i in range(len(z["lengths"])):
+        assert crc32(z["signals"][i, :z["lengths"][i]]) == g["zc_crc"][i], i
+    assert bits_equal(z["res7"], g["zc_res7"])
+    passed = (z["res7"][:, 0] == 1) & (z["res7"][:, 1] == z["type"])
+    counts = [int(passed[z["test"] == t].sum()) for t in range(5)]
+    counts[3] = int((passed & (np.abs(z["res7"][:, 4] - z["param"]) < 5.0))[z["test"] == 3].sum())
+    assert counts == g["zc_tool_pass_counts"].tolist() == [4, 4, 13, 7, 20]
+    # the program's thresholds: all of tests 0 / 1, 80 % of the sweep, 60 % of the CFO cases, 90 % of the discrimination trials
+    assert counts[0] == 4 and counts[1] == 4 and counts[2] >= 0.8 * 15 and counts[3] >= 0.6 * 7 and counts[4] >= 0.9 * 20
+
+
+def test_reference_test_programs_spreading_table(oracle, golden):
+    """tools/test_spreading.cpp: MC-DPSK DBPSK 1x / 2x / 4x + LDPC R1/2, -16 ... 0 dB; 5 of the program's 20 trials per cell
+    here (all 540 on the GPU).  Frames, soft bits, decoded bytes and the decode verdict are the reference's."""
+    g = golden("ref_tool_tables")
+    for mi, m in enumerate(g["sp_modes"]):
+        for si, snr in enumerate(g["sp_snrs"]):
+            for t in range(5):
+                c = oracle.tool_spreading_case(float(snr), int(m), 1000 + t)
+                assert np.array_equal(c["tx"], g["sp_tx"][t])
+                assert crc32(c["frame"]) == g["sp_frame_crc"][mi, si, t] and crc32(c["soft"]) == g["sp_soft_crc"][mi, si, t], (m, snr, t)
+                assert c["ok"] == g["sp_ok"][mi, si, t] and c["bit_errors"] == g["sp_bit_errors"][mi, si, t], (m, snr, t)
+                assert np.array_equal(c["decoded"], g["sp_decoded"][mi, si, t]), (m, snr, t)
+    table = ((g["sp_ok"] == 1) & (g["sp_bit_errors"] == 0)).sum(axis=2)
+    assert np.array_equal(table, g["sp_tool_success_table"])
+    # what the program is written to show: every mode decodes at 0 dB, and spreading moves the floor down
+    assert (table[:, -1] == 20).all() and table[2].sum() > table[1].sum() > table[0].sum()
+
+
+def test_reference_test_programs_chase_combining(oracle, golden):
+    """tools/test_chase_cache.cpp tests 1-3: 1.0 + 2.0 = 3.0 with two combines; 100 x 2 receptions at 2.5 dB and 50 x 4 at
+    1.5 dB from ONE generator, LLR sums formed left to right, LDPCCodec::decode of each"""
+    g = golden("ref_tool_tables")
+    import ctypes as C
+    acc, cnt = np.zeros(648, np.float32), C.c_int(0)
+    store = lambda v: oracle.lib.ro_chase_store(acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt), 0, np.full(648, v, np.float32).ctypes.data_as(C.POINTER(C.c_float)))
+    assert store(1.0) == 1 and cnt.value == 1
+    assert store(2.0) == 1 and cnt.value == 2 and (acc == 3.0).all()
+    l, ok = oracle.tool_chase_llrs()
+    assert [crc32(v) for v in l] == g["chase_llr_crc"].tolist()
+    assert np.array_equal(ok, g["chase_ok"])
+    t2, t3 = ok[:200].reshape(100, 2).sum(0), ok[200:].reshape(50, 3).sum(0)
+    assert [int(t2[0]), int(t2[1]), int(t3[0]), int(t3[1]), int(t3[2])] == g["chase_tool_counts"].tolist() == [27, 99, 2, 43, 50]
+    assert t2[1] > t2[0] + 10 and t3[2] > t3[1] > t3[0]          # the program's PASS conditions
