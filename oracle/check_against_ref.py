@@ -262,6 +262,17 @@ def main():
     (lo, oo), (lr, orr) = O.tool_chase_llrs(), R.tool_chase_llrs()
     check("tools/test_chase_cache.cpp receptions and decodes (400 codewords, 350 decodes)", bits_equal(lo, lr) and np.array_equal(oo, orr))
 
+    import gen_golden
+    ok, worst = True, ""
+    for snr, seed in gen_golden.zc_dbpsk_cases():
+        a, b = O.tool_zc_dbpsk_case(snr, seed), R.tool_zc_dbpsk_case(snr, seed)
+        same = (np.array_equal(a["tx"], b["tx"]) and bits_equal(a["signal"], b["signal"]) and bits_equal(a["zc7"], b["zc7"]) and a["stage"] == b["stage"]
+                and bits_equal(a["soft"], b["soft"]) and np.array_equal(a["decoded"], b["decoded"]) and a["ok"] == b["ok"] and a["bit_errors"] == b["bit_errors"])
+        ok &= same
+        if not same and not worst:
+            worst = f"snr={snr} seed={seed}"
+    check("tools/test_zc_dbpsk.cpp testAtSNR (130 cases: signal, ZC result, stage reached, soft bits, decode)", ok, worst)
+
     print("\n%s: %d failing group(s)" % ("PINNED" if fails == 0 else "MISMATCH", fails))
     return 1 if fails else 0
 

@@ -450,9 +450,20 @@ def run_tool(name):
     return subprocess.run([exe], capture_output=True, text=True, check=False, timeout=600).stdout
 
 
+def zc_dbpsk_cases():
+    """(snr, seed) of tools/test_zc_dbpsk.cpp:741-747 (sweep) and :773-777 (first step of the floor search, which ends there)"""
+    out = []
+    snr = np.float32(-15.0)
+    while snr <= np.float32(10.0):
+        out += [(float(snr), int(np.float32(snr * np.float32(1000)) + np.float32(t)) & 0xFFFFFFFF) for t in range(10)]
+        snr = np.float32(snr + np.float32(2.5))
+    out += [(-5.0, int(np.float32(-5000.0) + np.float32(t + 1000)) & 0xFFFFFFFF) for t in range(20)]
+    return out
+
+
 def tool_tables_fixture(R):
     """The scenarios of the reference's own test programs for this path (tools/test_zc_sync.cpp, tools/test_spreading.cpp,
-    tools/test_chase_cache.cpp), rebuilt by oracle/ref_shim_tools.cpp, with the reference's results; the programs are also run
+    tools/test_chase_cache.cpp, tools/test_zc_dbpsk.cpp), rebuilt by oracle/ref_shim_tools.cpp, with the reference's results; the programs are also run
     and what they print (correlations, pass counts, the success table) is checked against the rebuilt scenarios and recorded.
     Inputs are recorded as CRC-32 only: the restatement regenerates them anywhere (tests/test_oracle_golden.py)."""
     rec = {}
@@ -497,7 +508,32 @@ def tool_tables_fixture(R):
     printed = [int(a) for a in re.findall(r":\s+(\d+)/(?:100|50) \(", txt)]
     assert printed == [int(t2[0]), int(t2[1]), int(t3[0]), int(t3[1]), int(t3[2])], (printed, t2, t3)
     rec["chase_tool_counts"] = np.array(printed, np.int32)
-    print("tool tables: zc", counts, "spreading", table.tolist(), "chase", printed)
+    # ---- test_zc_dbpsk: the 11 x 10 sweep (seed = uint32(snr * 1000 + trial)) and the first step of the floor search (-5 dB, 20 trials)
+    cases = zc_dbpsk_cases()
+    rec["zcd_snr"] = np.array([c[0] for c in cases], np.float32); rec["zcd_seed"] = np.array([c[1] for c in cases], np.uint32)
+    L = {k: [] for k in ("sig_crc", "zc7", "stage", "soft_crc", "decoded", "ok", "bit_errors", "tx")}
+    for snr, seed in cases:
+        c = R.tool_zc_dbpsk_case(snr, seed)
+        L["sig_crc"].append(crc(c["signal"])); L["zc7"].append(c["zc7"]); L["stage"].append(c["stage"]); L["soft_crc"].append(crc(c["soft"]))
+        L["decoded"].append(c["decoded"]); L["ok"].append(c["ok"]); L["bit_errors"].append(c["bit_errors"]); L["tx"].append(c["tx"])
+    rec["zcd_sig_crc"] = np.array(L["sig_crc"], np.uint32); rec["zcd_zc7"] = np.stack(L["zc7"]); rec["zcd_stage"] = np.array(L["stage"], np.int32)
+    rec["zcd_soft_crc"] = np.array(L["soft_crc"], np.uint32); rec["zcd_decoded"] = np.stack(L["decoded"]); rec["zcd_ok"] = np.array(L["ok"], np.uint8)
+    rec["zcd_bit_errors"] = np.array(L["bit_errors"], np.int32); rec["zcd_tx"] = np.stack(L["tx"])
+    good = (rec["zcd_ok"] == 1) & (rec["zcd_bit_errors"] == 0)
+    sync = rec["zcd_zc7"][:110, 0].reshape(11, 10).sum(1).astype(np.int32); dec = good[:110].reshape(11, 10).sum(1).astype(np.int32)
+    txt = run_tool("test_zc_dbpsk")
+    rows = re.findall(r"^\s+(-?\d+\.\d)\s+(\d+\.\d)\s+(\d+\.\d)\s+(\d\.\d+)\s+(\d\.\d+)\s*$", txt, re.M)
+    assert len(rows) == 11 and [int(float(r[1])) for r in rows] == (sync * 10).tolist() and [int(float(r[2])) for r in rows] == (dec * 10).tolist(), (rows, sync, dec)
+    corr = rec["zcd_zc7"][:110, 3].reshape(11, 10)
+    for r, cc in zip(rows, corr):   # the program sums result.sync_corr in float, trial by trial, and prints the mean to 3 decimals
+        acc = np.float32(0)
+        for v in cc:
+            acc = np.float32(acc + v)
+        assert abs(float(np.float32(acc / np.float32(10))) - float(r[4])) < 0.00051, (r, cc)
+    floor = re.search(r"SNR=-5.0 dB: ([0-9.]+)% success", txt)
+    assert floor and int(float(floor.group(1))) == int(good[110:].sum()) * 5, (floor, good[110:].sum())
+    rec["zcd_tool_sync_counts"] = sync; rec["zcd_tool_decode_counts"] = dec; rec["zcd_tool_floor_m5_count"] = np.int32(good[110:].sum())
+    print("tool tables: zc", counts, "spreading", table.tolist(), "chase", printed, "zc_dbpsk sync", sync.tolist(), "decode", dec.tolist(), "floor(-5 dB)", int(good[110:].sum()))
     return rec
 
 

@@ -423,6 +423,37 @@ class Oracle:
             ok += [dec(a), dec(a + b), dec(((a + b) + c) + d)]
         return l, np.array(ok, np.uint8)
 
+    def tool_zc_dbpsk_case(self, snr_db, seed):
+        """tools/test_zc_dbpsk.cpp testAtSNR: silence + ZC (DATA) + MC-DPSK DBPSK frame + silence in noise -> ZCSync::detect ->
+        the demodulator from start_sample with the ZC's CFO (81 expected bytes = 65 data symbols) -> 648 soft bits -> decodeBP at
+        the decoder's default factor 0.75.  stage: 0 no sync, 1 bad start, 2 frame not ready, 4 decode failed, 5 decoded"""
+        rng = self._rng(seed)
+        tx = np.array([self.lib.ro_mt_next(C.byref(rng)) & 0xFF for _ in range(40)], np.uint8)
+        frame = self.mcdpsk_modulate(10, 1, 1, self.ldpc_encode(R1_2, tx))
+        z = np.zeros(500, np.float32)
+        sig = self.tool_add_noise(np.concatenate([z, self.zc_generate(5), frame, z]), snr_db, rng)
+        zc7 = self.zc_detect(sig, 0.2)
+        out = dict(tx=tx, signal=sig, zc7=zc7, soft=np.zeros(648, np.float32), decoded=np.zeros(40, np.uint8), sync=int(zc7[0]), ok=0, bit_errors=0, stage=0)
+        if not out["sync"]:
+            return out
+        start = int(zc7[2])
+        out["stage"] = 1
+        if start < 0 or start >= len(sig) - 1000:
+            return out
+        out["stage"] = 2
+        need = (8 + 1 + 65) * 512
+        dpsk = sig[start:len(sig) - 500]
+        if len(dpsk) < need:
+            return out
+        soft, _ = self.mcdpsk_demod(10, 1, 1, dpsk[:need], float(zc7[4]), 0.0)
+        out["stage"] = 4
+        out["soft"] = soft[:648].copy()
+        ok, dec, _ = self.ldpc_decode(R1_2, out["soft"], 80, 0.75)
+        if not ok:
+            return out
+        out.update(stage=5, ok=1, decoded=dec[:40].copy(), bit_errors=int(np.unpackbits(dec[:40] ^ tx).sum()))
+        return out
+
     def gather_table(self, bps, use_channel=True):
         t = np.zeros(4 * CW_BITS, np.int32)
         self.lib.ro_rx_gather_table(bps, int(use_channel), ip(t))
@@ -479,6 +510,7 @@ class Ref:
         L.ref_tool_zc_cases.argtypes = [_f, C.c_int, _i, _i, _i, _f, _f, C.c_int]
         L.ref_tool_spreading_case.argtypes = [C.c_float, C.c_int, C.c_uint32, _u8, _f, C.c_int, _i, _f, C.c_int, _u8, _i]
         L.ref_tool_chase_llrs.argtypes = [_f, _u8]
+        L.ref_tool_zc_dbpsk_case.argtypes = [C.c_float, C.c_uint32, _u8, _f, C.c_int, _f, _f, _u8, _i]
         L.ref_quiet()
 
     # ---- the scenarios of the reference's own test programs (oracle/ref_shim_tools.cpp)
@@ -506,6 +538,14 @@ class Ref:
         n = self.lib.ref_tool_chase_llrs(fp(l), up(ok))
         assert n == 400, n
         return l, ok
+
+    def tool_zc_dbpsk_case(self, snr_db, seed):
+        """tools/test_zc_dbpsk.cpp testAtSNR -> dict(tx, signal, zc7, soft, decoded, sync, ok, bit_errors, stage)"""
+        sig = np.zeros(50000, np.float32); zc7 = np.zeros(7, np.float32); soft = np.zeros(648, np.float32)
+        tx = np.zeros(40, np.uint8); dec = np.zeros(40, np.uint8); out4 = np.zeros(4, np.int32)
+        n = self.lib.ref_tool_zc_dbpsk_case(snr_db, seed & 0xFFFFFFFF, up(tx), fp(sig), len(sig), fp(zc7), fp(soft), up(dec), ip(out4))
+        assert n > 0, n
+        return dict(tx=tx, signal=sig[:n].copy(), zc7=zc7, soft=soft, decoded=dec, sync=int(out4[0]), ok=int(out4[1]), bit_errors=int(out4[2]), stage=int(out4[3]))
 
     def channel_cfo(self, kind, snr_db, seed, x, cfo_hz=0.0, random_cfo_max_hz=0.0):
         x = np.ascontiguousarray(x, np.float32)

@@ -6,7 +6,8 @@
 //   tools/test_zc_sync.cpp     tests 0-4: ZC preambles in silence / noise / with a CFO        -> ref_tool_zc_cases
 //   tools/test_spreading.cpp   testAtSNR: LDPC R1/2 + MC-DPSK DBPSK 1x / 2x / 4x in noise      -> ref_tool_spreading_case
 //   tools/test_chase_cache.cpp tests 2-3: noisy BPSK codewords, LLR sums of 2 / 4 receptions   -> ref_tool_chase_llrs
-// oracle/Makefile also builds those three programs unmodified (make tools); oracle/check_against_ref.py runs them and
+//   tools/test_zc_dbpsk.cpp    testAtSNR: ZC preamble + MC-DPSK DBPSK + LDPC R1/2 in noise          -> ref_tool_zc_dbpsk_case
+// oracle/Makefile also builds those programs unmodified (make tools); oracle/check_against_ref.py runs them and
 // compares their printed tables with what these builders give.  std::mt19937 / std::normal_distribution are the library's;
 // the few lines of signal arithmetic (noise scaling, CFO rotation) restate the cited helper functions of those programs.
 
@@ -232,6 +233,73 @@ int ref_tool_chase_llrs(float* llrs, uint8_t* ok_out) {
         ok_out[k++] = codec.decode(c4).first ? 1 : 0;
     }
     return w;
+}
+
+// tools/test_zc_dbpsk.cpp:50-232 testAtSNR(snr_db, seed): 500 samples of silence + ZC preamble (DATA) + MC-DPSK DBPSK
+// (level4_dbpsk) training / reference / LDPC R1/2 data + 500 of silence -> noise -> ZCSync::detect(0.2) -> the demodulator's
+// process() from start_sample with the ZC's CFO and 81 expected bytes -> 648 soft bits -> LDPCCodec::decode.
+// signal_out [max_n], zc7 as ref_zc_detect's out7, soft648, tx40 / decoded40; out4 = {sync detected, data decoded, bit errors,
+// stage reached: 0 no sync, 1 bad start_sample, 2 frame not ready, 3 fewer than 648 soft bits, 4 decode failed, 5 decoded}.
+// Returns the signal length.
+int ref_tool_zc_dbpsk_case(float snr_db, uint32_t seed, uint8_t* tx40, float* signal_out, int max_n, float* zc7, float* soft648,
+                           uint8_t* decoded40, int* out4) {
+    ultra::g_log_level = LogLevel::NONE;
+    std::mt19937 rng(seed);
+    sync::ZCSync zc_sync = tool_zc();
+    MultiCarrierDPSKConfig cfg = mc_dpsk_presets::level4_dbpsk();
+    cfg.use_dual_chirp = false;
+    MultiCarrierDPSKModulator mod(cfg);
+    MultiCarrierDPSKDemodulator demod(cfg);
+    fec::LDPCCodec ldpc(CodeRate::R1_2);
+    const int data_bytes = 40;
+    Bytes tx_data(data_bytes);
+    for (int i = 0; i < data_bytes; i++) tx_data[i] = rng() & 0xFF;
+    std::memcpy(tx40, tx_data.data(), data_bytes);
+    Samples zc_preamble = zc_sync.generatePreamble(sync::ZCFrameType::DATA);
+    Samples training = mod.generateTrainingSequence();
+    Samples ref = mod.generateReferenceSymbol();
+    Bytes encoded = ldpc.encode(tx_data);
+    mod.reset();
+    Samples data = mod.modulate(encoded);
+    Samples sig(500, 0.0f);
+    sig.insert(sig.end(), zc_preamble.begin(), zc_preamble.end());
+    sig.insert(sig.end(), training.begin(), training.end());
+    sig.insert(sig.end(), ref.begin(), ref.end());
+    sig.insert(sig.end(), data.begin(), data.end());
+    sig.resize(sig.size() + 500, 0.0f);
+    tool_add_noise(sig, snr_db, rng);
+    const int n = static_cast<int>(sig.size());
+    if (n > max_n) return -n;
+    std::memcpy(signal_out, sig.data(), sig.size() * sizeof(float));
+    std::memset(soft648, 0, 648 * sizeof(float)); std::memset(decoded40, 0, data_bytes);
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    auto r = zc_sync.detect(SampleSpan(sig.data(), sig.size()), 0.2f, false);
+    zc7[0] = r.detected ? 1.f : 0.f; zc7[1] = static_cast<float>(static_cast<int>(r.frame_type)); zc7[2] = static_cast<float>(r.start_sample);
+    zc7[3] = r.correlation; zc7[4] = r.cfo_hz; zc7[5] = r.snr_estimate; zc7[6] = static_cast<float>(r.root_detected);
+    out4[0] = r.detected ? 1 : 0;
+    if (!r.detected) return n;
+    out4[3] = 1;
+    int start = r.start_sample;
+    if (start < 0 || start >= static_cast<int>(sig.size()) - 1000) return n;
+    out4[3] = 2;
+    Samples dpsk(sig.begin() + start, sig.end() - 500);
+    demod.reset();
+    demod.setExpectedDataBytes(encoded.size());
+    demod.setChirpDetected(r.cfo_hz);
+    if (!demod.process(SampleSpan(dpsk.data(), dpsk.size()))) return n;
+    out4[3] = 3;
+    auto soft = demod.getSoftBits();
+    if (soft.size() < 648) return n;
+    out4[3] = 4;
+    soft.resize(648);
+    std::memcpy(soft648, soft.data(), 648 * sizeof(float));
+    auto [success, decoded] = ldpc.decode(soft);
+    if (!success || decoded.empty()) return n;
+    out4[3] = 5;
+    out4[1] = 1;
+    std::memcpy(decoded40, decoded.data(), data_bytes);
+    for (int i = 0; i < data_bytes; i++) out4[2] += __builtin_popcount(static_cast<unsigned>(tx_data[i] ^ decoded[i]));
+    return n;
 }
 
 }  // extern "C"

@@ -3,6 +3,7 @@
   tools/test_spreading.cpp    the 3 x 9 x 20 success table (MC-DPSK DBPSK 1x / 2x / 4x + LDPC R1/2, -16 ... 0 dB)
                                            -> ria_gpu_mcdpsk_demod_batch + ria_gpu_ldpc_decode_batch
   tools/test_chase_cache.cpp  tests 1-3  -> ria_gpu_chase_combine_batch + ria_gpu_ldpc_decode_batch
+  tools/test_zc_dbpsk.cpp     testAtSNR, 130 cases -> ria_gpu_sync_zc_batch -> ria_gpu_mcdpsk_demod_batch -> ria_gpu_ldpc_decode_batch
 The inputs are those programs' own signals: rebuilt by the CPU restatement (oracle.tool_*), CRC-32 checked against what the
 compiled reference produced with the library's mt19937 / normal_distribution (tests/golden/ref_tool_tables.npz, made by
 oracle/gen_golden.py from oracle/ref_shim_tools.cpp while the programs themselves ran and their printed tables were compared).
@@ -105,3 +106,54 @@ def test_chase_cache_program_scenarios(oracle, golden):
     t2, t3 = ok[:200].reshape(100, 2).sum(0), ok[200:].reshape(50, 3).sum(0)
     assert [int(t2[0]), int(t2[1]), int(t3[0]), int(t3[1]), int(t3[2])] == g["chase_tool_counts"].tolist()
     assert t2[1] > t2[0] + 10 and t3[2] > t3[1] > t3[0]                # the program's PASS conditions (:194,:251)
+
+
+def test_zc_dbpsk_program_chain(oracle, golden):
+    """tools/test_zc_dbpsk.cpp: all 130 testAtSNR cases of its sweep and floor search through the device: ZC detection on the
+    41 400-sample capture (the long-buffer path), then - exactly as the program chains them - the MC-DPSK demodulator from the
+    ZC's start_sample with the ZC's CFO estimate and 65 data symbols, 648 soft bits, one LDPC decode at the decoder's default
+    factor.  Cases the program abandons (no sync, start too late for a whole frame) are abandoned at the same stage."""
+    import torch
+    e = engine("QAM16", "R1_2")
+    g = golden("ref_tool_tables")
+    n = len(g["zcd_snr"])
+    sigs = [oracle.tool_zc_dbpsk_case(float(g["zcd_snr"][i]), int(g["zcd_seed"][i]))["signal"] for i in range(n)]
+    assert all(crc32(sigs[i]) == g["zcd_sig_crc"][i] for i in range(n)) and len({len(s) for s in sigs}) == 1
+    X = dev(np.stack(sigs))
+    r = e.sync_zc(X, threshold=0.2, root_mask=15)
+    zc7 = np.stack([r[k].astype(np.float32) for k in ("detected", "frame_type", "start_sample", "correlation", "cfo_hz", "snr_estimate", "root_detected")], axis=1)
+    assert np.array_equal(bits(zc7), bits(g["zcd_zc7"])), np.nonzero(bits(zc7) != bits(g["zcd_zc7"]))
+    need, L = (8 + 1 + 65) * 512, X.shape[1]
+    stage = np.zeros(n, np.int32)
+    rows = []
+    for i in range(n):
+        if not r["detected"][i]:
+            continue
+        start = int(r["start_sample"][i])
+        stage[i] = 1
+        if start < 0 or start >= L - 1000:                              # test_zc_dbpsk.cpp:142-147
+            continue
+        stage[i] = 2
+        if L - 500 - start < need:                                      # process() is not ready without training + reference + 65 symbols
+            continue
+        stage[i] = 4
+        rows.append(i)
+    frames = torch.stack([X[i, int(r["start_sample"][i]):int(r["start_sample"][i]) + need] for i in rows]).contiguous()
+    llr, _ = e.mcdpsk_demod(frames, 10, 1, 1, cfo_hz=dev(r["cfo_hz"][rows].astype(np.float32)), phase0=dev(np.zeros(len(rows), np.float32)))
+    soft = llr[:, :648].contiguous()
+    out, ok, _ = e.ldpc_decode(soft, 80, 0.75)
+    soft, out, ok = soft.cpu().numpy(), out.cpu().numpy(), ok.cpu().numpy()
+    good = np.zeros(n, bool)
+    for k, i in enumerate(rows):
+        assert crc32(soft[k]) == g["zcd_soft_crc"][i], i
+        assert int(ok[k]) == g["zcd_ok"][i], i
+        if ok[k]:
+            stage[i] = 5
+            errs = int(np.unpackbits(out[k, :40] ^ g["zcd_tx"][i]).sum())
+            assert np.array_equal(out[k, :40], g["zcd_decoded"][i]) and errs == g["zcd_bit_errors"][i], i
+            good[i] = errs == 0
+    assert np.array_equal(stage, g["zcd_stage"]), np.nonzero(stage != g["zcd_stage"])
+    # the table the program printed: Sync% and Decode% per SNR, and the first step of its floor search
+    assert r["detected"][:110].reshape(11, 10).sum(1).tolist() == g["zcd_tool_sync_counts"].tolist()
+    assert good[:110].reshape(11, 10).sum(1).tolist() == g["zcd_tool_decode_counts"].tolist()
+    assert int(good[110:].sum()) == int(g["zcd_tool_floor_m5_count"])

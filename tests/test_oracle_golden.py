@@ -512,3 +512,20 @@ def test_reference_test_programs_chase_combining(oracle, golden):
     t2, t3 = ok[:200].reshape(100, 2).sum(0), ok[200:].reshape(50, 3).sum(0)
     assert [int(t2[0]), int(t2[1]), int(t3[0]), int(t3[1]), int(t3[2])] == g["chase_tool_counts"].tolist() == [27, 99, 2, 43, 50]
     assert t2[1] > t2[0] + 10 and t3[2] > t3[1] > t3[0]          # the program's PASS conditions
+
+
+def test_reference_test_programs_zc_dbpsk_chain(oracle, golden):
+    """tools/test_zc_dbpsk.cpp testAtSNR: ZC preamble + MC-DPSK DBPSK + LDPC R1/2 in noise, synchronised by ZCSync::detect and
+    demodulated from its start_sample with its CFO estimate.  Every third case of the program's 130 here (all on the GPU):
+    signal, ZCSyncResult, the stage the program reached (no sync / frame not ready / decode failed / decoded), soft bits, bytes."""
+    g = golden("ref_tool_tables")
+    for i in range(0, len(g["zcd_snr"]), 3):
+        c = oracle.tool_zc_dbpsk_case(float(g["zcd_snr"][i]), int(g["zcd_seed"][i]))
+        assert np.array_equal(c["tx"], g["zcd_tx"][i]) and crc32(c["signal"]) == g["zcd_sig_crc"][i], i
+        assert bits_equal(c["zc7"], g["zcd_zc7"][i]) and c["stage"] == g["zcd_stage"][i], (i, c["zc7"], g["zcd_zc7"][i])
+        assert crc32(c["soft"]) == g["zcd_soft_crc"][i] and c["ok"] == g["zcd_ok"][i] and c["bit_errors"] == g["zcd_bit_errors"][i], i
+        assert np.array_equal(c["decoded"], g["zcd_decoded"][i]), i
+    good = (g["zcd_ok"] == 1) & (g["zcd_bit_errors"] == 0)
+    assert good[:110].reshape(11, 10).sum(1).tolist() == g["zcd_tool_decode_counts"].tolist() == [0, 0, 0, 4, 8, 9, 8, 9, 10, 10, 10]
+    assert g["zcd_zc7"][:110, 0].reshape(11, 10).sum(1).tolist() == g["zcd_tool_sync_counts"].tolist() == [3] + [10] * 10
+    assert {0, 2, 4, 5} <= set(g["zcd_stage"].tolist())        # every exit of the program's chain occurs in the table
