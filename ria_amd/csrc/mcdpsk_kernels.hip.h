@@ -1,17 +1,20 @@
 // ria_amd/csrc/mcdpsk_kernels.hip.h — multi-carrier DPSK demodulator and the HARQ
 // chase combine (a19).
 //
-// mcdpsk_demod_kernel: MultiCarrierDPSKDemodulator driven as MCDPSKWaveform::process drives it after an
+// mcdpsk_corr / chain / stats / llr kernels: MultiCarrierDPSKDemodulator driven as MCDPSKWaveform::process drives it after an
 // external chirp detection (mc_dpsk_waveform.cpp:322-332 -> processGotChirp, multi_carrier_dpsk.hpp:797-896):
 // applyCFOCorrection (:901-926, Hilbert FIR src/dsp/filters.cpp:266-317) -> processTraining (:473-505, its
 // estimate is reported but not applied, :857-861) -> setReference (:507-518) -> demodulateSoft (:520-736),
-// one workgroup per frame, bit-exact:
+// four kernels over a chunk of frames, bit-exact:
 //   * every (symbol, carrier) correlation is a left-to-right float sum over 512 samples against the
 //     carrier's mixer e^{-j*phase_i}; phase_i is a float recurrence that restarts at every symbol, so the
-//     mixer is a per-carrier table built once on the host; one LANE per (symbol, carrier);
+//     mixer is a per-carrier table built once on the host; one lane per (carrier, 4 consecutive symbols), samples and
+//     mixer staged through LDS a chunk of the symbol at a time (mcdpsk_corr_kernel, one workgroup per frame);
 //   * the differential chain, the noise/magnitude statistics and the reliability weights are short ordered
-//     loops -> one lane (or one lane per carrier), values parked in LDS;
-//   * LLRs: one lane per (data symbol, carrier);
+//     loops: kernels of their own with one LANE per (carrier, frame) / per frame over item-major tables
+//     (mcdpsk_chain_kernel, mcdpsk_stats_kernel) - inside the per-frame workgroup they ran on 1-10 of its 256
+//     lanes and were half of the time;
+//   * LLRs: one lane per (frame, data symbol, carrier) (mcdpsk_llr_kernel);
 //   * CFO correction: the 127-tap Hilbert FIR is one lane per output sample (ordered 127-term sum); the
 //     rotation phase is a wrapped float recurrence over the whole frame -> one lane walks it while the
 //     other waves filter.
@@ -27,41 +30,54 @@ namespace ria {
 constexpr int kMcSps = 512, kMcTrain = 8, kMcMaxCarriers = 20, kMcHilbertTaps = 127;
 
 struct McArgs {
-    const float* samples; long long stride; int frame_samples; int n_frames; int first;
+    const float* samples; long long stride; int frame_samples; int n_frames; int first;   // n_frames: this chunk, from frame `first`
     int nc, bps, spreading;
     const float* cfo; const float* phase0;
     const float2* mixer;       // [nc][512]
     const float* hilbert;      // [127]
-    float* ws;                 // [chunk][2][frame_samples] corrected samples | rotation phases
+    int chunk;                 // samples of a symbol staged per pass of the correlations (mcdpsk_corr_chunk)
+    float* ws;                 // [n_frames][2][frame_samples] corrected samples | rotation phases (frames with a CFO)
+    // per-chunk tables between the kernels, ITEM-major ([item][n_frames]) so that one-lane-per-frame kernels read them coalesced
+    float2* Yg;                // [n_sym * nc][n_frames]  correlations / 512 (training 0, training 1, reference, data ...)
+    float* cph; float* cmag; float* pe2;   // [nds * nc][n_frames]
+    float* rel;                // [kMcMaxCarriers][n_frames]
+    float* scale;              // [n_frames]
     float* llr; int llr_stride;
     ria_mcdpsk_status* status;
 };
 
 __device__ __forceinline__ float2 mc_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-__global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
+struct McShape { int n, num_rx, nds, n_sym; };
+// floats per staged sample row: the frame's symbols rounded up to whole groups of four, never a multiple of 32 (LDS banks)
+__host__ __device__ inline int mc_sym_row(int n_sym) { int r = (n_sym + 3) & ~3; if ((r & 31) == 0) r += 4; return r; }
+__device__ __forceinline__ McShape mc_shape(const McArgs& A) {
+    McShape g;
+    g.n = A.frame_samples;
+    g.num_rx = (g.n - (kMcTrain + 1) * kMcSps) / kMcSps;
+    g.nds = g.num_rx / A.spreading;
+    if (g.nds < 1) g.nds = 1;
+    g.n_sym = 3 + g.num_rx;                       // training 0, training 1, reference, data...
+    return g;
+}
+// the CFO the demodulator keeps after its correction (:901-926): corrected frames continue with 0
+__device__ __forceinline__ bool mc_corrects(float cfo, int n) { return fabs_(cfo) > 0.1f && !(fabs_(cfo) < 0.01f) && n >= 128; }
+
+// ---- kernel 1: one workgroup per frame: CFO correction (:901-926) and the (symbol, carrier) correlations (:931-946)
+__global__ __launch_bounds__(256) void mcdpsk_corr_kernel(McArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, f = blockIdx.x;
-    const int nc = A.nc, bps = A.bps, sp = A.spreading, n = A.frame_samples;
-    const int local_preamble = (kMcTrain + 1) * kMcSps;
-    const int data_samples = n - local_preamble;
-    const int num_rx = data_samples / kMcSps;
-    int nds = num_rx / sp;
-    if (nds < 1) nds = 1;
-    const int n_sym = 3 + num_rx;                 // training 0, training 1, reference, data...
-    // LDS carve-up
-    float2* mix = reinterpret_cast<float2*>(smem);                         // [nc][512]
-    float2* Y = mix + nc * kMcSps;                                         // [n_sym][nc]
-    float* cph = reinterpret_cast<float*>(Y + n_sym * nc);                 // [nds][nc]
-    float* cmag = cph + nds * nc;                                          // [nds][nc]
-    float* pe2 = cmag + nds * nc;                                          // [nds][nc]
-    float* rel = pe2 + nds * nc;                                           // [nc] + scalars
-    float* scal = rel + kMcMaxCarriers;                                    // [8]
+    const McShape g = mc_shape(A);
+    const int nc = A.nc, n = g.n, n_sym = g.n_sym;
+    // staging of one chunk of every symbol: SAMPLE-major rows of S4 symbols (a lane reads the same sample of its 4 consecutive
+    // symbols as one 16-byte word), and the mixer carrier-major in padded rows (two consecutive values per 16-byte word)
+    const int CH = A.chunk, chs = 31 - __builtin_clz(static_cast<unsigned>(CH)), S4 = mc_sym_row(n_sym), mrow = CH + 2;
+    float2* Y = reinterpret_cast<float2*>(smem);                           // [n_sym][nc]  running sums
+    float* xs_l = reinterpret_cast<float*>(smem + ((n_sym * nc * 8 + 15) & ~15));   // [CH][S4]
+    float2* mx_l = reinterpret_cast<float2*>(xs_l + CH * S4);              // [nc][mrow]
     const float* x = A.samples + static_cast<long long>(A.first + f) * A.stride;
-    for (int i = tid; i < nc * kMcSps; i += 256) mix[i] = A.mixer[i];
-    // ---- CFO correction (:901-926)
-    float cfo = A.cfo ? A.cfo[A.first + f] : 0.0f;
-    if (fabs_(cfo) > 0.1f && !(fabs_(cfo) < 0.01f) && n >= 128) {
+    const float cfo = A.cfo ? A.cfo[A.first + f] : 0.0f;
+    if (mc_corrects(cfo, n)) {
         float* xc = A.ws + static_cast<size_t>(f) * 2 * n;
         float* ph = xc + n;
         if (tid == 0) {
@@ -87,32 +103,78 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
         }
         __syncthreads();
         x = xc;
-        cfo = 0.0f;
     }
-    __syncthreads();
-    // ---- correlations (:931-946): task (symbol s, carrier c); s = 0,1 training, 2 reference, 3.. data
-    for (int task = tid; task < n_sym * nc; task += 256) {
-        const int s = task / nc, c = task - s * nc;
-        const int sym_index = (s < 2) ? s : (s == 2 ? kMcTrain : kMcTrain + 1 + (s - 3));
-        const float* xs = x + sym_index * kMcSps;
-        const float2* m = mix + c * kMcSps;
-        // the two left-to-right sums advance together as one packed multiply and one packed add per sample (the IEEE
-        // operations of the halves; the build no longer SLP-packs, and here the packed form is the faster one: measured)
-        typedef float pk2 __attribute__((ext_vector_type(2)));
-        pk2 acc = {0.0f, 0.0f};
-        for (int i = 0; i < kMcSps; ++i) {
-            const float v = xs[i];
-            const float2 w = m[i];
-            acc = acc + pk2{v, v} * pk2{w.x, w.y};
+    // task (symbol s, carrier c); s = 0,1 training, 2 reference, 3.. data.  A lane owns one carrier and FOUR consecutive
+    // symbols: per sample it reads the mixer value once and the four symbols' samples as one word, and advances four
+    // independent pairs of left-to-right sums, each pair as one packed multiply and one packed add (the IEEE operations of
+    // the halves).  The running sums stay in Y between the chunks, so the order of every sum is the reference's.
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    const int T = n_sym * nc, n_grp = (n_sym + 3) / 4, G = n_grp * nc;
+    for (int t = tid; t < T; t += 256) Y[t] = make_float2(0.0f, 0.0f);
+    for (int i0 = 0; i0 < kMcSps; i0 += CH) {
+        __syncthreads();
+        for (int idx = tid; idx < n_sym * CH; idx += 256) {                 // CH is a power of two
+            const int s = idx >> chs, i = idx & (CH - 1);
+            const int sym_index = (s < 2) ? s : (s == 2 ? kMcTrain : kMcTrain + 1 + (s - 3));
+            xs_l[i * S4 + s] = x[sym_index * kMcSps + i0 + i];
         }
-        const float sr = acc.x, si = acc.y;
-        Y[task] = make_float2(fdiv(sr, static_cast<float>(kMcSps)), fdiv(si, static_cast<float>(kMcSps)));
+        for (int idx = tid; idx < (S4 - n_sym) * CH; idx += 256) {          // symbols beyond the frame in the last group: zeros
+            const int s = n_sym + (idx >> chs), i = idx & (CH - 1);
+            xs_l[i * S4 + s] = 0.0f;
+        }
+        for (int idx = tid; idx < nc * CH; idx += 256) {
+            const int c = idx >> chs, i = idx & (CH - 1);
+            mx_l[c * mrow + i] = A.mixer[c * kMcSps + i0 + i];
+        }
+        __syncthreads();
+        for (int gi = tid; gi < G; gi += 256) {
+            const int sg = gi / nc, c = gi - sg * nc, s0 = 4 * sg;
+            pk2 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 a = (s0 + j < n_sym) ? Y[(s0 + j) * nc + c] : make_float2(0.0f, 0.0f);
+                acc[j] = pk2{a.x, a.y};
+            }
+            const float* xp = xs_l + s0;
+            const float2* mp = mx_l + c * mrow;
+#pragma unroll 2
+            for (int i = 0; i < CH; i += 2) {
+                const float4 w = *reinterpret_cast<const float4*>(mp + i);                 // mixer values i, i + 1
+                const float4 xa = *reinterpret_cast<const float4*>(xp + i * S4), xb = *reinterpret_cast<const float4*>(xp + (i + 1) * S4);
+                acc[0] = acc[0] + pk2{xa.x, xa.x} * pk2{w.x, w.y};
+                acc[1] = acc[1] + pk2{xa.y, xa.y} * pk2{w.x, w.y};
+                acc[2] = acc[2] + pk2{xa.z, xa.z} * pk2{w.x, w.y};
+                acc[3] = acc[3] + pk2{xa.w, xa.w} * pk2{w.x, w.y};
+                acc[0] = acc[0] + pk2{xb.x, xb.x} * pk2{w.z, w.w};
+                acc[1] = acc[1] + pk2{xb.y, xb.y} * pk2{w.z, w.w};
+                acc[2] = acc[2] + pk2{xb.z, xb.z} * pk2{w.z, w.w};
+                acc[3] = acc[3] + pk2{xb.w, xb.w} * pk2{w.z, w.w};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s0 + j < n_sym) Y[(s0 + j) * nc + c] = make_float2(acc[j].x, acc[j].y);
+        }
     }
     __syncthreads();
-    // ---- per-carrier differential chain (setReference + demodulateSoft pass 1), one lane per carrier
-    if (tid < nc) {
-        const int c = tid;
-        float2 prev = Y[2 * nc + c];
+    for (int t = tid; t < T; t += 256) {
+        const float2 a = Y[t];
+        A.Yg[static_cast<size_t>(t) * A.n_frames + f] = make_float2(fdiv(a.x, static_cast<float>(kMcSps)), fdiv(a.y, static_cast<float>(kMcSps)));
+    }
+}
+
+// ---- kernel 2: the per-carrier differential chain (setReference :507-518 + demodulateSoft pass 1 :520-560): serial over the
+// data symbols, so one LANE per (carrier, frame), frames adjacent
+__global__ __launch_bounds__(256) void mcdpsk_chain_kernel(McArgs A) {
+    const McShape g = mc_shape(A);
+    const int nc = A.nc, bps = A.bps, sp = A.spreading, num_rx = g.num_rx, nds = g.nds;
+    const size_t F = static_cast<size_t>(A.n_frames);
+    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= F * nc) return;
+    const int c = static_cast<int>(idx / F);
+    const size_t f = idx - static_cast<size_t>(c) * F;
+    auto Y = [&](int item) { return A.Yg[static_cast<size_t>(item) * F + f]; };
+    {
+        float2 prev = Y(2 * nc + c);
         const float a = hypotf_glibc(prev.x, prev.y);
         if (a > 0.001f) { const float a2 = hypotf_glibc(prev.x, prev.y); prev = make_float2(fdiv(prev.x, a2), fdiv(prev.y, a2)); }
         else prev = make_float2(1.0f, 0.0f);
@@ -122,7 +184,7 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
             for (int rep = 0; rep < sp; ++rep) {
                 const int rs = ds * sp + rep;
                 if (rs >= num_rx) break;
-                const float2 cur = Y[(3 + rs) * nc + c];
+                const float2 cur = Y((3 + rs) * nc + c);
                 comb.x += cur.x; comb.y += cur.y;
             }
             comb.x = fdiv(comb.x, static_cast<float>(sp)); comb.y = fdiv(comb.y, static_cast<float>(sp));
@@ -143,16 +205,29 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
             }
             while (pe > kPi) pe -= 2.0f * kPi;
             while (pe < -kPi) pe += 2.0f * kPi;
-            cph[ds * nc + c] = phase; cmag[ds * nc + c] = mag; pe2[ds * nc + c] = pe * pe;
+            const size_t o = static_cast<size_t>(ds * nc + c) * F + f;
+            A.cph[o] = phase; A.cmag[o] = mag; A.pe2[o] = pe * pe;
         }
     }
-    __syncthreads();
-    // ---- ordered statistics, processTraining, reliability weights: one lane
-    if (tid == 0) {
+}
+
+// ---- kernel 3: processTraining (:473-505), the ordered statistics of demodulateSoft (:560-640), the DBPSK reliability weights
+// and the fading indices (:404-437, :705-733): short serial loops over a frame's symbols, so one LANE per frame
+__global__ __launch_bounds__(64) void mcdpsk_stats_kernel(McArgs A) {
+    const McShape g = mc_shape(A);
+    const int nc = A.nc, bps = A.bps, nds = g.nds;
+    const size_t F = static_cast<size_t>(A.n_frames);
+    const size_t f = static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (f >= F) return;
+    auto Y = [&](int item) { return A.Yg[static_cast<size_t>(item) * F + f]; };
+    auto cmag = [&](int item) { return A.cmag[static_cast<size_t>(item) * F + f]; };
+    const float cfo_in = A.cfo ? A.cfo[A.first + f] : 0.0f;
+    const float cfo_after = mc_corrects(cfo_in, g.n) ? 0.0f : cfo_in;
+    {
         // processTraining (:473-505)
         float psum = 0.0f;
         for (int c = 0; c < nc; ++c) {
-            const float2 s0 = Y[c], s1 = Y[nc + c];
+            const float2 s0 = Y(c), s1 = Y(nc + c);
             const float expected_phase = static_cast<float>(static_cast<double>(c) * 3.14159265358979323846 / static_cast<double>(2.0f));
             const float2 ed = make_float2(1.0f * cosf_glibc(expected_phase), 1.0f * sinf_glibc(expected_phase));
             const float2 ad = mc_cmul(s1, make_float2(s0.x, -s0.y));
@@ -164,16 +239,16 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
         const float residual = static_cast<float>(static_cast<double>(avg) / (static_cast<double>(2.0f) * 3.14159265358979323846 * static_cast<double>(symbol_duration)));
         // statistics of demodulateSoft (:560-640)
         float noise_sum = 0.0f;
-        for (int i = 0; i < nds * nc; ++i) noise_sum += pe2[i];
+        for (int i = 0; i < nds * nc; ++i) noise_sum += A.pe2[static_cast<size_t>(i) * F + f];
         const int noise_count = nds * nc;
         float mag_sum[kMcMaxCarriers], mag_sq[kMcMaxCarriers];
         for (int c = 0; c < nc; ++c) { mag_sum[c] = 0.0f; mag_sq[c] = 0.0f; }
         int valid = nds;
         {
             for (int ds = 0; ds < nds; ++ds)
-                for (int c = 0; c < nc; ++c) { const float m = cmag[ds * nc + c]; mag_sum[c] += m; mag_sq[c] += m * m; }
+                for (int c = 0; c < nc; ++c) { const float m = cmag(ds * nc + c); mag_sum[c] += m; mag_sq[c] += m * m; }
             if (nds >= 4) {
-                auto sym_total = [&](int ds) { float t = 0.0f; for (int c = 0; c < nc; ++c) t += cmag[ds * nc + c]; return t; };
+                auto sym_total = [&](int ds) { float t = 0.0f; for (int c = 0; c < nc; ++c) t += cmag(ds * nc + c); return t; };
                 float ref_mag = 0.0f;
                 for (int s = 0; s < 4; ++s) ref_mag += sym_total(s);
                 ref_mag = fdiv(ref_mag, 4.0f);
@@ -183,7 +258,7 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
                     if (valid < nds) {
                         for (int c = 0; c < nc; ++c) { mag_sum[c] = 0.0f; mag_sq[c] = 0.0f; }
                         for (int s = 0; s < valid; ++s)
-                            for (int c = 0; c < nc; ++c) { const float m = cmag[s * nc + c]; mag_sum[c] += m; mag_sq[c] += m * m; }
+                            for (int c = 0; c < nc; ++c) { const float m = cmag(s * nc + c); mag_sum[c] += m; mag_sq[c] += m * m; }
                     }
                 }
             }
@@ -192,6 +267,7 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
         pnv = (0.01f < pnv) ? pnv : 0.01f;
         float scale = 2.0f * fsqrt(fdiv(1.0f, pnv));
         scale = (20.0f < scale) ? 20.0f : scale;
+        float rel[kMcMaxCarriers];
         for (int c = 0; c < nc; ++c) rel[c] = 1.0f;
         if (bps == 1 && valid > 0) {
             float mean_mag[kMcMaxCarriers];
@@ -220,7 +296,8 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
                 rel[c] = (0.12f < t2) ? t2 : 0.12f;
             }
         }
-        scal[0] = scale;
+        A.scale[f] = scale;
+        for (int c = 0; c < nc; ++c) A.rel[static_cast<size_t>(c) * F + f] = rel[c];
         // fading indices (:404-437, :705-733)
         float tfi = 0.0f;
         if (valid >= 4) {
@@ -249,35 +326,54 @@ __global__ __launch_bounds__(256) void mcdpsk_demod_kernel(McArgs A) {
             }
         }
         ria_mcdpsk_status st;
-        st.cfo_hz = cfo; st.fading_index = ffi + 1.0f * tfi; st.freq_fading_index = ffi; st.temporal_fading_index = tfi;
+        st.cfo_hz = cfo_after; st.fading_index = ffi + 1.0f * tfi; st.freq_fading_index = ffi; st.temporal_fading_index = tfi;
         st.training_cfo_residual = residual; st.n_llr = nds * nc * bps; st.valid_symbols = valid; st.reserved = 0;
         A.status[A.first + f] = st;
     }
-    __syncthreads();
-    // ---- LLRs (:650-667)
-    const float scale = scal[0];
+}
+
+// ---- kernel 4: LLRs (:650-667), one lane per (frame, data symbol, carrier)
+__global__ __launch_bounds__(256) void mcdpsk_llr_kernel(McArgs A) {
+    const McShape g = mc_shape(A);
+    const int nc = A.nc, bps = A.bps, per = g.nds * nc;
+    const size_t F = static_cast<size_t>(A.n_frames);
+    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= F * per) return;
+    const size_t f = idx / per;
+    const int i = static_cast<int>(idx - f * per), c = i % nc;
+    const float phase = A.cph[static_cast<size_t>(i) * F + f];
+    const float cs = A.scale[f] * A.rel[static_cast<size_t>(c) * F + f];
     float* out = A.llr + static_cast<size_t>(A.first + f) * A.llr_stride;
-    for (int i = tid; i < nds * nc; i += 256) {
-        const int c = i % nc;
-        const float phase = cph[i];
-        const float cs = scale * rel[c];
-        if (bps == 2) {
-            const float sb0 = cs * sinf_glibc(phase), sb1 = cs * sinf_glibc(2.0f * phase);
-            const float a = (sb0 < 20.0f) ? sb0 : 20.0f, b = (sb1 < 20.0f) ? sb1 : 20.0f;
-            out[2 * i] = (-20.0f < a) ? a : -20.0f;
-            out[2 * i + 1] = (-20.0f < b) ? b : -20.0f;
-        } else {
-            const float sb = cs * cosf_glibc(phase);
-            const float a = (sb < 20.0f) ? sb : 20.0f;
-            out[i] = (-20.0f < a) ? a : -20.0f;
-        }
+    if (bps == 2) {
+        const float sb0 = cs * sinf_glibc(phase), sb1 = cs * sinf_glibc(2.0f * phase);
+        const float a = (sb0 < 20.0f) ? sb0 : 20.0f, b = (sb1 < 20.0f) ? sb1 : 20.0f;
+        out[2 * i] = (-20.0f < a) ? a : -20.0f;
+        out[2 * i + 1] = (-20.0f < b) ? b : -20.0f;
+    } else {
+        const float sb = cs * cosf_glibc(phase);
+        const float a = (sb < 20.0f) ? sb : 20.0f;
+        out[i] = (-20.0f < a) ? a : -20.0f;
     }
 }
 
-__host__ __device__ inline int mcdpsk_lds_bytes(int nc, int frame_samples, int spreading) {
+// samples of a symbol staged per pass of the correlations: the largest power of two whose padded rows (every symbol of the
+// frame + every carrier's mixer) stay within 48 KB, so that three workgroups share a CU
+__host__ __device__ inline int mcdpsk_corr_chunk(int nc, int frame_samples) {
+    const int n_sym = 3 + (frame_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
+    int ch = 128;
+    while (ch > 8 && mc_sym_row(n_sym) * ch * 4 + nc * (ch + 2) * 8 > 48 * 1024) ch >>= 1;
+    return ch;
+}
+__host__ __device__ inline int mcdpsk_lds_bytes(int nc, int frame_samples) {
+    const int n_sym = 3 + (frame_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
+    const int ch = mcdpsk_corr_chunk(nc, frame_samples);
+    return ((n_sym * nc * 8 + 15) & ~15) + mc_sym_row(n_sym) * ch * 4 + nc * (ch + 2) * 8 + 64;
+}
+// floats of per-chunk workspace per frame: the CFO-corrected samples and phases (with_cfo), Yg, cph / cmag / pe2, rel, scale
+__host__ __device__ inline size_t mcdpsk_ws_floats_per_frame(int nc, int frame_samples, int spreading, bool with_cfo) {
     const int num_rx = (frame_samples - (kMcTrain + 1) * kMcSps) / kMcSps;
     int nds = num_rx / spreading; if (nds < 1) nds = 1;
-    return nc * kMcSps * 8 + (3 + num_rx) * nc * 8 + 3 * nds * nc * 4 + (kMcMaxCarriers + 8) * 4 + 64;
+    return (with_cfo ? 2 * static_cast<size_t>(frame_samples) : 0) + 2 * static_cast<size_t>(3 + num_rx) * nc + 3 * static_cast<size_t>(nds) * nc + kMcMaxCarriers + 1;
 }
 
 // MultiCarrierDPSKModulator on the device (multi_carrier_dpsk.hpp:141-281): training (8 symbols) + reference + data audio

@@ -1368,18 +1368,20 @@ int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, c
         h->d_mc_mixer[nc] = p;
     }
     if (!h->d_mc_hilbert) { std::vector<float> hc = build_hilbert127(); HIP_TRY(h, upload(&h->d_mc_hilbert, hc)); }
-    const int lds = mcdpsk_lds_bytes(nc, frame_samples, cfg->spreading);
+    const int lds = mcdpsk_lds_bytes(nc, frame_samples);
     if (lds > 160 * 1024) return fail(h, RIA_ERR_UNSUPPORTED, "ria_gpu_mcdpsk_demod_batch: frame too long for one workgroup's LDS");
     if (lds > h->mc_lds_opted) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mcdpsk_demod_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mcdpsk_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         h->mc_lds_opted = lds;
     }
-    // CFO-corrected samples + rotation phases live in a workspace: chunks of frames when a CFO array is given
-    const int chunk = cfo_hz_dev ? std::min(n_frames, 1024) : n_frames;
-    if (cfo_hz_dev) {
-        const size_t need = static_cast<size_t>(chunk) * 2 * frame_samples;
+    // the tables handed from kernel to kernel (and the CFO-corrected samples when a CFO array is given) live in a per-handle
+    // workspace; a batch is walked in chunks of frames that fit it
+    const size_t per_frame = mcdpsk_ws_floats_per_frame(nc, frame_samples, cfg->spreading, cfo_hz_dev != nullptr);
+    const int chunk = static_cast<int>(std::min<size_t>(static_cast<size_t>(n_frames), std::max<size_t>(1, (size_t(256) << 20) / (per_frame * sizeof(float)))));
+    {
+        const size_t need = static_cast<size_t>(chunk) * per_frame + 64;
         if (need > h->mc_ws_floats) {
-            if (h->d_mc_ws) (void)hipFree(h->d_mc_ws);
+            if (h->d_mc_ws) { HIP_TRY(h, hipStreamSynchronize(s)); (void)hipFree(h->d_mc_ws); }
             h->d_mc_ws = nullptr; h->mc_ws_floats = 0;
             HIP_TRY(h, hipMalloc(&h->d_mc_ws, need * sizeof(float)));
             h->mc_ws_floats = need;
@@ -1388,11 +1390,25 @@ int ria_gpu_mcdpsk_demod_batch(ria_gpu_handle h, const ria_mcdpsk_config* cfg, c
     McArgs A{};
     A.samples = samples_dev; A.stride = stride; A.frame_samples = frame_samples; A.nc = nc; A.bps = cfg->bits_per_symbol;
     A.spreading = cfg->spreading; A.cfo = cfo_hz_dev; A.phase0 = phase0_dev; A.mixer = static_cast<const float2*>(h->d_mc_mixer[nc]);
-    A.hilbert = static_cast<const float*>(h->d_mc_hilbert); A.ws = static_cast<float*>(h->d_mc_ws); A.llr = llr_out_dev;
-    A.llr_stride = llr_stride; A.status = status_dev;
+    A.hilbert = static_cast<const float*>(h->d_mc_hilbert); A.llr = llr_out_dev;
+    A.llr_stride = llr_stride; A.status = status_dev; A.chunk = mcdpsk_corr_chunk(nc, frame_samples);
+    const size_t n_sym = static_cast<size_t>(3 + num_rx);
     for (int first = 0; first < n_frames; first += chunk) {
         A.first = first; A.n_frames = std::min(chunk, n_frames - first);
-        hipLaunchKernelGGL(mcdpsk_demod_kernel, dim3(A.n_frames), dim3(256), lds, s, A);
+        const size_t F = static_cast<size_t>(A.n_frames);
+        float* p = static_cast<float*>(h->d_mc_ws);
+        A.ws = p; if (cfo_hz_dev) p += F * 2 * frame_samples;
+        p = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p) + 15) & ~uintptr_t(15));
+        A.Yg = reinterpret_cast<float2*>(p); p += 2 * n_sym * nc * F;
+        A.cph = p; p += static_cast<size_t>(nds) * nc * F;
+        A.cmag = p; p += static_cast<size_t>(nds) * nc * F;
+        A.pe2 = p; p += static_cast<size_t>(nds) * nc * F;
+        A.rel = p; p += static_cast<size_t>(kMcMaxCarriers) * F;
+        A.scale = p;
+        hipLaunchKernelGGL(mcdpsk_corr_kernel, dim3(A.n_frames), dim3(256), lds, s, A);
+        hipLaunchKernelGGL(mcdpsk_chain_kernel, dim3(static_cast<unsigned>((F * nc + 255) / 256)), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(mcdpsk_stats_kernel, dim3(static_cast<unsigned>((F + 63) / 64)), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(mcdpsk_llr_kernel, dim3(static_cast<unsigned>((F * nds * nc + 255) / 256)), dim3(256), 0, s, A);
     }
     HIP_TRY(h, hipGetLastError());
     return RIA_OK;
