@@ -396,6 +396,47 @@ def test_config_c2_dqpsk_demod_only_full_size(oracle):
     assert ok > 0.97, ok
 
 
+def test_config3_literal_size_batch_properties(oracle):
+    """BASELINE config 3 at its literal size: 100 000 QAM16 R1/2 frames through Watterson moderate 20 dB in ONE ria_gpu_rx_batch
+    call (the bench step).  Size-independent properties over the whole batch: (1) the call is a function of its input - a
+    second call returns the same bytes and status records; (2) batch-size independence - the same frames in four calls of
+    25 000 (other part boundaries, other work-list sizes, other queue interleavings) give the same records frame for frame;
+    (3) decodeFixedFrame's contract holds on every frame - frame_valid exactly where all four codewords are reported decoded,
+    no bytes for a codeword that is not, nothing left flagged for recovery, attempts within the cascade's 1 ... 39; (4) the decoded share is
+    the workload's (64 % +- 2); and a sample of 96 frames spread over the batch equals the CPU chain bit for bit."""
+    import torch
+    from ria_amd.engine import RxEngine
+    n = 100000
+    e = RxEngine("QAM16", "R1_2", max_batch=n)
+    info, x = _bench_batch(e, n, 0)
+    out1, st1 = e.rx(x)
+    out2, st2 = e.rx(x)
+    assert torch.equal(out1, out2) and torch.equal(st1, st2)
+    outs, sts = [], []
+    for k in range(4):
+        o, s_ = e.rx(x[25000 * k:25000 * (k + 1)])
+        outs.append(o.clone()); sts.append(s_.clone())
+    assert torch.equal(torch.cat(outs), out1) and torch.equal(torch.cat(sts), st1)
+    s = e.decode_status(st1)
+    assert not s["needs_recovery"].any() and not (s["reserved"][:, 1] == 0xEE).any()
+    okf = s["cw_ok"].all(axis=1)
+    assert np.array_equal(okf, s["frame_valid"].astype(bool))
+    o = out1.cpu().numpy()
+    assert (o.reshape(n, 4, 40)[~s["cw_ok"].astype(bool)] == 0).all()        # a codeword that is not reported decoded carries no bytes
+    assert s["attempts"].min() >= 1 and s["attempts"].max() <= 39
+    share = okf.mean()
+    assert 0.62 < share < 0.66, share
+    same = (o == info.cpu().numpy()).all(axis=1)
+    assert (same & ~okf).sum() == 0 and same[okf].mean() > 0.97      # CRC-16 recoveries the reference accepts are not all the sent frame
+    idx = np.linspace(0, n - 1, 96).astype(int)
+    xs = x[torch.from_numpy(idx).to(x.device)].cpu().numpy()
+    for q, f in enumerate(idx):
+        llr, _ = oracle.rx_process(po.QAM16, po.R1_2, xs[q])
+        d, ok, it, att = oracle.decode_fixed_frame(llr, po.R1_2, True, 188, flags=7)
+        assert np.array_equal(ok, s["cw_ok"][f]) and np.array_equal(d, o[f]), f
+        assert np.array_equal(s["iterations"][f], it.astype(np.uint16)) and np.array_equal(s["attempts"][f], att.astype(np.uint8)), f
+
+
 def test_bench_rccl_code_path_on_one_rank():
     """bench.py's N > 1 collectives (RCCL broadcast of the seed, all-reduce of counters and time, barrier) executed on this
     box's GPU with a one-rank process group (RIA_BENCH_FORCE_DIST=1): the line must carry the same metric and workload as
