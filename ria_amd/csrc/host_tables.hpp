@@ -333,17 +333,21 @@ struct CoreLayout {
 };
 
 namespace bankopt {
-// one half-wave gather: LDS passes = worst bank multiplicity (distinct words per bank); word < 0: the lane
-// reads its own zero word.  Returns kPassWeight * passes + sum of squared multiplicities: the second term
-// only breaks ties, it gives the annealer a slope on the plateaus of the max.
+// one half-wave gather: LDS passes = worst bank multiplicity (distinct words per bank); word < 0: a padded slot or an idle
+// lane, which reads a constant word (+0.0 on the column side, the "big" total on the row side) of which there is a copy in
+// every bank: the table builder points all of them at the copy in a bank the real reads of this gather leave free (one
+// address: a broadcast), so they cost nothing.  Returns kPassWeight * passes + sum of squared multiplicities: the second
+// term only breaks ties, it gives the annealer a slope on the plateaus of the max.
 constexpr int kPassWeight = 64;
 inline int half_cost(const int* word, int lane0) {
+    (void)lane0;
     int cnt[32] = {0};
     int seen[32][8];
     int worst = 1;
     for (int l = 0; l < 32; ++l) {
-        const int w = word[l] < 0 ? -(lane0 + l) - 1 : word[l];
-        const int b = word[l] < 0 ? (lane0 + l) & 31 : (w & 31);
+        if (word[l] < 0) continue;
+        const int w = word[l];
+        const int b = w & 31;
         bool dup = false;
         for (int i = 0; i < cnt[b] && i < 8; ++i) dup = dup || seen[b][i] == w;
         if (dup) continue;
@@ -573,37 +577,52 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
     for (size_t q = 0; q < L.col_at.size(); ++q) if (L.col_at[q] >= 0) t.col_at[q] = static_cast<uint16_t>(L.col_at[q]);
     t.col_pos.resize(k);
     for (int j = 0; j < k; ++j) t.col_pos[j] = static_cast<uint16_t>(L.col_pos[j]);
+    // Padded slots and idle lanes read a constant word; every one of the 64 big / zero words holds the same value, so the lanes
+    // of a half-wave gather all take the copy in a bank its real reads leave free (-1 below, resolved per half wave)
+    auto resolve_padding = [](std::vector<int>& w64, int const_word) {
+        for (int h = 0; h < 2; ++h) {
+            bool used[32] = {false};
+            int real = 0;
+            for (int l = 32 * h; l < 32 * h + 32; ++l) if (w64[l] >= 0) { used[w64[l] & 31] = true; ++real; }
+            int b = 0;
+            while (b < 31 && used[b]) ++b;                 // fewer than 32 real reads leave a bank free
+            (void)real;
+            for (int l = 32 * h; l < 32 * h + 32; ++l) if (w64[l] < 0) w64[l] = const_word + b;
+        }
+    };
     t.row_addr.assign(static_cast<size_t>(64) * std::max(1, t.ts), 0);
     for (int r = 0; r < L.NR; ++r)
-        for (int l = 0; l < 64; ++l) {
-            const int i = L.check_at[64 * r + l];
-            for (int s = 0; s < L.ne[r]; ++s) {
-                int w = t.big_word + l;   // padded slot (or idle lane): the lane's big word (ldpc_fast.hip.h: kPadTotal)
-                if (i >= 0 && s < static_cast<int>(L.row_cols[i].size())) w = t.tot_word + L.col_pos[L.row_cols[i][s]];
-                t.row_addr[static_cast<size_t>(64) * (L.row_off[r] + s) + l] = static_cast<uint16_t>(4 * w);
+        for (int s = 0; s < L.ne[r]; ++s) {
+            std::vector<int> w64(64, -1);                  // padded slot (or idle lane): a big word (ldpc_fast.hip.h: kPadTotal)
+            for (int l = 0; l < 64; ++l) {
+                const int i = L.check_at[64 * r + l];
+                if (i >= 0 && s < static_cast<int>(L.row_cols[i].size())) w64[l] = t.tot_word + L.col_pos[L.row_cols[i][s]];
             }
+            resolve_padding(w64, t.big_word);
+            for (int l = 0; l < 64; ++l) t.row_addr[static_cast<size_t>(64) * (L.row_off[r] + s) + l] = static_cast<uint16_t>(4 * w64[l]);
         }
     t.col_addr.assign(static_cast<size_t>(64) * std::max(1, t.td), 0);
     for (int cr = 0; cr < L.NC; ++cr)
-        for (int l = 0; l < 64; ++l) {
-            const int cc = L.col_at[64 * cr + l];
-            for (int d = 0; d < L.dv[cr]; ++d) {
-                int w = t.zero_word + l;
+        for (int d = 0; d < L.dv[cr]; ++d) {
+            std::vector<int> w64(64, -1);                  // padded slot (or idle lane): a zero word
+            for (int l = 0; l < 64; ++l) {
+                const int cc = L.col_at[64 * cr + l];
                 if (cc >= 0 && d < static_cast<int>(L.col_checks[cc].size())) {
                     const int i = L.col_checks[cc][d];
                     int s = 0;
                     while (L.row_cols[i][s] != cc) ++s;
-                    w = 64 * (L.row_off[L.row_pos[i] / 64] + s) + L.row_pos[i] % 64;
+                    w64[l] = 64 * (L.row_off[L.row_pos[i] / 64] + s) + L.row_pos[i] % 64;
                 }
-                t.col_addr[static_cast<size_t>(64) * (L.col_off[cr] + d) + l] = static_cast<uint16_t>(4 * w);
             }
+            resolve_padding(w64, t.zero_word);
+            for (int l = 0; l < 64; ++l) t.col_addr[static_cast<size_t>(64) * (L.col_off[cr] + d) + l] = static_cast<uint16_t>(4 * w64[l]);
         }
     return t;
 }
 
 // ---- shipped layouts -------------------------------------------------------------------------------
-// The annealer is deterministic but slow to converge (152 conflict passes per iteration after 1 M moves, 140 after
-// 16 M), so the layouts of the six rates are annealed offline by tools/gen_core_layouts.cpp and shipped as data
+// The annealer is deterministic but slow to converge (R1/2: 120 conflict passes per iteration after 2 M moves, 110 after
+// 32 M; floor 98), so the layouts of the six rates are annealed offline by tools/gen_core_layouts.cpp and shipped as data
 // (core_layouts.inc).  A shipped layout is used only after validate_core_tables() has checked it against the H the
 // library generates: every address table entry must be the one the decoder's indexing scheme implies.
 struct SavedCoreTables { int rate; int n; const uint16_t* data; };
@@ -671,29 +690,27 @@ inline bool validate_core_tables(const LdpcCode& c, const CoreTables& t) {
                 const int q = w - t.tot_word;
                 if (q < 0 || q >= 64 * NC || t.col_at[q] == 0xFFFF) return false;
                 got.push_back(t.col_at[q]);
-            } else if (w != t.big_word + l) return false;
+            } else if (w < t.big_word || w >= t.big_word + 64) return false;   // a padded slot reads any of the big words
         }
         slot_col[i] = got;
         std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
         if (want != got) return false;
     }
     for (int r = 0; r < NR; ++r) for (int l = 0; l < 64; ++l) if (t.check_at[64 * r + l] == 0xFFFF)
-        for (int s = 0; s < t.ne[r]; ++s) if (t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l] != 4 * (t.big_word + l)) return false;
+        for (int s = 0; s < t.ne[r]; ++s) { const int a = t.row_addr[static_cast<size_t>(64) * (row_off[r] + s) + l]; if (a % 4 || a / 4 < t.big_word || a / 4 >= t.big_word + 64) return false; }
     for (int cr = 0; cr < NC; ++cr) for (int l = 0; l < 64; ++l) {
         const int cc = t.col_at[64 * cr + l] == 0xFFFF ? -1 : t.col_at[64 * cr + l];
         const int deg = cc < 0 ? 0 : static_cast<int>(col_checks[cc].size());
         if (deg > t.dv[cr]) return false;
         for (int d = 0; d < t.dv[cr]; ++d) {
             const int a = t.col_addr[static_cast<size_t>(64) * (col_off[cr] + d) + l];
-            int w = t.zero_word + l;
             if (d < deg) {
                 const int i = col_checks[cc][d];
                 int s = -1;
                 for (size_t q = 0; q < slot_col[i].size(); ++q) if (slot_col[i][q] == cc) s = static_cast<int>(q);
                 if (s < 0) return false;
-                w = 64 * (row_off[row_pos[i] / 64] + s) + row_pos[i] % 64;
-            }
-            if (a != 4 * w) return false;
+                if (a != 4 * (64 * (row_off[row_pos[i] / 64] + s) + row_pos[i] % 64)) return false;
+            } else if (a % 4 || a / 4 < t.zero_word || a / 4 >= t.zero_word + 64) return false;   // a padded slot reads any of the zero words
         }
     }
     return true;
