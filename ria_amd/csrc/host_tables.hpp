@@ -622,7 +622,7 @@ inline CoreTables build_core_tables(const LdpcCode& c, int optimiser_moves = 120
 
 // ---- shipped layouts -------------------------------------------------------------------------------
 // The annealer is deterministic but slow to converge (R1/2: 120 conflict passes per iteration after 2 M moves, 110 after
-// 32 M; floor 98), so the layouts of the six rates are annealed offline by tools/gen_core_layouts.cpp and shipped as data
+// 32 M, 107 after 128 M; floor 98), so the layouts of the six rates are annealed offline by tools/gen_core_layouts.cpp and shipped as data
 // (core_layouts.inc).  A shipped layout is used only after validate_core_tables() has checked it against the H the
 // library generates: every address table entry must be the one the decoder's indexing scheme implies.
 struct SavedCoreTables { int rate; int n; const uint16_t* data; };
