@@ -437,6 +437,39 @@ def test_config3_literal_size_batch_properties(oracle):
         assert np.array_equal(s["iterations"][f], it.astype(np.uint16)) and np.array_equal(s["attempts"][f], att.astype(np.uint8)), f
 
 
+def test_config4_and_config5_drivers_run_and_resume(tmp_path):
+    """tools/run_ladder_sweep.py (config 5) and tools/run_acquisition_grid.py (config 4) as a user runs them on one GPU: a sweep
+    interrupted after some points and resumed gives the table of an uninterrupted one (per-point counters are functions of
+    (seed, point, global trial) only), and a second --resume has nothing left to do; the grid driver's counters have the shape of
+    the committed 20 000-preamble table."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    sweep_cmd = [sys.executable, os.path.join(root, "tools", "run_ladder_sweep.py"), "--trials", "256", "--chunk", "128", "--channels", "0,2",
+                 "--snr-min", "-14", "--snr-max", "22", "--snr-step", "12"]
+    full = str(tmp_path / "full.jsonl"); part = str(tmp_path / "part.jsonl")
+    a = json.loads(subprocess.run(sweep_cmd + ["--out", full], env=env, capture_output=True, text=True, check=True, timeout=600).stdout.strip().splitlines()[-1])
+    assert a["points"] == 8 and a["points_run_now"] == 8
+    lines = open(full).read().splitlines()
+    open(part, "w").write("\n".join(lines[:3]) + "\n")                  # the run "died" after three points
+    b = json.loads(subprocess.run(sweep_cmd + ["--out", part, "--resume"], env=env, capture_output=True, text=True, check=True, timeout=600).stdout.strip().splitlines()[-1])
+    assert b["points_run_now"] == 5
+    strip = lambda rows: [{k: v for k, v in r.items() if k != "seconds"} for r in rows]
+    assert strip(b["table"]) == strip(a["table"])
+    assert strip([json.loads(x) for x in open(part).read().splitlines()]) == strip(a["table"])
+    c = json.loads(subprocess.run(sweep_cmd + ["--out", part, "--resume"], env=env, capture_output=True, text=True, check=True, timeout=600).stdout.strip().splitlines()[-1])
+    assert c["points_run_now"] == 0 and strip(c["table"]) == strip(a["table"])
+    g = json.loads(subprocess.run([sys.executable, os.path.join(root, "tools", "run_acquisition_grid.py"), "--preambles", "64"], env=env,
+                                  capture_output=True, text=True, check=True, timeout=600).stdout.strip().splitlines()[-1])
+    assert len(g["table"]) == 25 and all(r["n"] == 64 for r in g["table"])
+    # the table of profiles/*_acquisition_grid.json at 20 000 preambles per point: the dual chirp finds 99-100 % everywhere, ZC (given
+    # the grid's CFO as known_cfo) nothing at -10 dB and 67-78 % from 0 dB up, and whatever it detects it times correctly
+    assert all(r["chirp_success"] >= 60 and r["chirp_timing_ok"] >= 60 for r in g["table"])
+    assert all(r["zc_detected"] == 0 for r in g["table"] if r["snr_db"] == -10.0)
+    assert all(30 <= r["zc_detected"] <= 60 for r in g["table"] if r["snr_db"] >= 0.0)
+    assert all(r["zc_timing_ok"] == r["zc_detected"] for r in g["table"])
+
+
 def test_bench_rccl_code_path_on_one_rank():
     """bench.py's N > 1 collectives (RCCL broadcast of the seed, all-reduce of counters and time, barrier) executed on this
     box's GPU with a one-rank process group (RIA_BENCH_FORCE_DIST=1): the line must carry the same metric and workload as
